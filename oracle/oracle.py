@@ -1,0 +1,122 @@
+"""ctypes/numpy loader for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see the header of spmm_oracle.c).  Nothing under
+cuda-optimization-for-spmm_amd/ imports it.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only, no GPU)."""
+    src = os.path.join(_HERE, "spmm_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liboracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_spmm_csr_f32.argtypes = [ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
+        _lib.oracle_spmm_csr_f32.restype = None
+        _lib.oracle_spmm_coo_f32.argtypes = [ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
+        _lib.oracle_spmm_coo_f32.restype = None
+        _lib.oracle_spmm_ell_colmajor_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
+        _lib.oracle_spmm_ell_colmajor_f32.restype = None
+        _lib.oracle_spmm_bsr_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
+        _lib.oracle_spmm_bsr_f32.restype = None
+        _lib.oracle_dense_reorder_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _f32p, _f32p, ctypes.c_int]
+        _lib.oracle_dense_reorder_f32.restype = None
+        _lib.oracle_allclose_f32.argtypes = [ctypes.c_size_t, _f32p, _f32p, ctypes.c_double, ctypes.c_double]
+        _lib.oracle_allclose_f32.restype = ctypes.c_int
+    return _lib
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(_u32p)
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+def spmm_csr(row_ptrs, col_idxs, data, b):
+    """C = A_csr @ B with the reference's CSR CPU numerics (double accumulate)."""
+    rp, rpp = _u32(row_ptrs)
+    ci, cip = _u32(col_idxs)
+    da, dap = _f32(data)
+    bb, bp = _f32(b)
+    m = rp.shape[0] - 1
+    n = bb.shape[1]
+    c = np.zeros((m, n), dtype=np.float32)
+    lib().oracle_spmm_csr_f32(m, rpp, cip, dap, bp, n, c.ctypes.data_as(_f32p))
+    return c
+
+
+def spmm_coo(num_rows, row_idxs, col_idxs, data, b):
+    ri, rip = _u32(row_idxs)
+    ci, cip = _u32(col_idxs)
+    da, dap = _f32(data)
+    bb, bp = _f32(b)
+    n = bb.shape[1]
+    c = np.zeros((num_rows, n), dtype=np.float32)
+    lib().oracle_spmm_coo_f32(da.shape[0], rip, cip, dap, bp, n, c.ctypes.data_as(_f32p))
+    return c
+
+
+def spmm_ell_colmajor(num_rows, row_idxs, data, b):
+    """row_idxs/data: [numCols, maxColNnz]; pad index 0xFFFFFFFF."""
+    ri, rip = _u32(row_idxs)
+    da, dap = _f32(data)
+    bb, bp = _f32(b)
+    num_cols, width = ri.shape
+    n = bb.shape[1]
+    c = np.zeros((num_rows, n), dtype=np.float32)
+    lib().oracle_spmm_ell_colmajor_f32(num_cols, width, rip, dap, bp, n, c.ctypes.data_as(_f32p))
+    return c
+
+
+def spmm_bsr(num_rows, block_row_size, block_col_size, block_row_ptrs, block_col_idxs, data, b):
+    rp, rpp = _u32(block_row_ptrs)
+    ci, cip = _u32(block_col_idxs)
+    da, dap = _f32(data)
+    bb, bp = _f32(b)
+    n = bb.shape[1]
+    c = np.zeros((num_rows, n), dtype=np.float32)
+    lib().oracle_spmm_bsr_f32(rp.shape[0] - 1, block_row_size, block_col_size, rpp, cip, dap, bp, n,
+                              c.ctypes.data_as(_f32p))
+    return c
+
+
+def dense_reorder(src, num_rows, num_cols, to_col_major):
+    s, sp = _f32(np.asarray(src).reshape(-1))
+    d = np.empty(num_rows * num_cols, dtype=np.float32)
+    lib().oracle_dense_reorder_f32(num_rows, num_cols, sp, d.ctypes.data_as(_f32p), int(bool(to_col_major)))
+    return d
+
+
+def allclose(c, ref, rtol=1e-2, atol=1e-3):
+    """torch::allclose restatement; defaults are the reference's REL_TOL/ABS_TOL."""
+    a, ap = _f32(np.asarray(c).reshape(-1))
+    b, bp = _f32(np.asarray(ref).reshape(-1))
+    assert a.shape == b.shape
+    return bool(lib().oracle_allclose_f32(a.shape[0], ap, bp, rtol, atol))
