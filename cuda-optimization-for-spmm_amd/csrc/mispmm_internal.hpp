@@ -1,0 +1,38 @@
+// Internal helpers shared by the translation units of libmispmm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "mispmm.h"
+
+namespace mispmm {
+
+constexpr int kWave = 64;  // CDNA wavefront width; hard-coded on purpose
+
+// thread-local detail string behind mispmm_last_error()
+void set_error(const char *fmt, ...);
+int fail(int status, const char *fmt, ...);
+
+inline hipStream_t as_stream(mispmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define MISPMM_HIP_TRY(expr)                                                                          \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return ::mispmm::fail(e_ == hipErrorNoDevice ? MISPMM_ERR_NO_DEVICE : MISPMM_ERR_HIP,     \
+                                  "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                                  __LINE__);                                                          \
+    } while (0)
+
+// A launch that follows; picks up configuration errors without synchronising.
+#define MISPMM_LAUNCH_CHECK() MISPMM_HIP_TRY(hipGetLastError())
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace mispmm

@@ -1,0 +1,332 @@
+// BSR x dense SpMM for gfx950.  Blocks are bR x bC row-major, stored in block-CSR order.
+//
+// Replaces /root/reference/src/spmm/bsr/spmm_bsr_k1.cu (one thread per block element, an
+// atomicAdd per output element and term).  Three kernels, none with atomics:
+//   bsr_valu  any block shape.  A C row is a CSR row whose terms are (block, column-in-block)
+//             pairs: G lanes own one C row, the coefficients of 16 terms are fetched by one
+//             coalesced load and broadcast by shuffle, B rows come as dropped-or-live buffer
+//             loads.  Terms are summed block by block in storage order and by ascending column
+//             inside a block: REFERENCE mode reproduces spmmBSRCpu (spmm_bsr.cpp:17-38) bit for bit.
+//   bsr_mfma_f32   16x16 blocks on v_mfma_f32_16x16x4_f32: one wave owns a block row x 64 output
+//             columns (4 accumulator tiles).  The instruction is an exact k-ordered fp32 fma chain,
+//             and the k slots are mapped to ascending block columns, so the result equals the
+//             FAST VALU kernel's bit for bit.
+//   bsr_mfma_bf16  16x16 bf16 blocks on v_mfma_f32_16x16x32_bf16, two blocks per instruction
+//             (K = 32), fp32 accumulate, B transposed into operand order in registers (v_perm).
+// Output columns of a 64-wide super-tile are interleaved over the 4 accumulator tiles
+// (tile t, lane column c <-> column 4c + t), so B rows are read and C rows written as whole
+// 16-byte (fp32) / 8-byte (bf16) vectors.
+// Roofline: HBM for bf16 (algorithmic bytes nb*bR*bC*e + nb*4 + (Mb+1)*4 + K*N*e + M*N*o);
+// fp32 MFMA runs at the fp32 vector rate and is MFMA-bound on low-fill blocks.
+#include "spmm_common.hpp"
+
+namespace mispmm {
+
+using f32x4_t = float __attribute__((ext_vector_type(4)));
+using bf16x8_t = short __attribute__((ext_vector_type(8)));
+using u32x2_t = uint32_t __attribute__((ext_vector_type(2)));
+using u32x4_t = uint32_t __attribute__((ext_vector_type(4)));
+
+// -------------------------------------------------------------------------------------- bsr_valu
+template <int G, int VEC, class Acc, bool WIDE>
+__global__ __launch_bounds__(256) void bsr_valu(uint32_t M, uint32_t bR, uint32_t bC,
+                                                const uint32_t *__restrict__ blockRowPtrs,
+                                                const uint32_t *__restrict__ blockColIdxs,
+                                                const float *__restrict__ blocks, const float *__restrict__ B,
+                                                uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
+                                                uint32_t ldc) {
+    constexpr int GROUPS = 256 / G;
+    constexpr int U = (VEC == 4) ? 8 : 16;
+    using vec_t = typename VecOf<VEC>::type;
+    const uint32_t lane = threadIdx.x % G;
+    const uint32_t row = blockIdx.x * GROUPS + threadIdx.x / G;
+    const uint32_t col0 = blockIdx.y * (G * VEC) + lane * VEC;
+    const bool row_ok = row < M;
+    const bool col_ok = col0 < N;
+    uint32_t bstart = 0, terms = 0, i_in = 0;
+    if (row_ok) {
+        const uint32_t R = row / bR;
+        i_in = row - R * bR;
+        bstart = blockRowPtrs[R];
+        terms = (blockRowPtrs[R + 1] - bstart) * bC;
+    }
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;
+    const float *bcol = B + (col_ok ? col0 : 0);
+
+    for (uint32_t base = 0; base < terms; base += G) {
+        const uint32_t cnt = min(static_cast<uint32_t>(G), terms - base);
+        const uint32_t t = base + min(lane, cnt - 1);  // term index inside the block row
+        const uint32_t b = bstart + t / bC;
+        const uint32_t j = t % bC;
+        const uint32_t my_brow = blockColIdxs[b] * bC + j;  // B row of this term
+        const float my_val = blocks[(static_cast<size_t>(b) * bR + i_in) * bC + j];
+        for (uint32_t q = 0; q < cnt; q += U) {
+            vec_t bv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t src = (q + u) & (G - 1);
+                const float a = __shfl(my_val, src, G);
+                const bool live = q + u < cnt;
+                if constexpr (WIDE) {
+                    const uint32_t r = __shfl(my_brow, live ? src : (cnt - 1) & (G - 1), G);
+                    bv[u] = load_vec<VEC>(bcol + static_cast<size_t>(r) * ldb);
+                    av[u] = a;
+                } else {
+                    const uint32_t off = __shfl(my_brow, src, G) * (ldb * 4u);
+                    bv[u] = buffer_load_vec<VEC>(rsrc, live ? off + lane_off : kDropLoad, 0);
+                    av[u] = live ? a : 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!WIDE || q + u < cnt) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
+                }
+            }
+        }
+    }
+    if (row_ok && col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------- bsr_mfma_f32
+// Work item = (block row R, 64-column super-tile st); one wave each, 4 per workgroup.
+// Lane l = (c = l & 15, g = l >> 4).  MFMA 16x16x4: A operand lane holds A[i = c][k = g],
+// B operand lane holds B[k = g][j = c]; D register r of lane l is D[row 4g + r][col c].
+// Step s of a block uses block columns 4s + g, so k runs over ascending columns.
+__global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
+                                                    const uint32_t *__restrict__ blockColIdxs,
+                                                    const float *__restrict__ blocks, const float *__restrict__ B,
+                                                    uint32_t N, uint32_t ldb, float *__restrict__ C, uint32_t ldc) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + wave;
+    if (item >= Mb * nST) return;  // wave-uniform
+    const uint32_t R = item / nST, st = item - R * nST;
+    const uint32_t c = lane & 15, g = lane >> 4;
+    const uint32_t ncol = st * 64 + c * 4;  // first of this lane's 4 interleaved output columns
+    const rsrc_t rsrc = make_rsrc(B, N * 4u);  // one B row; columns past N read as zero
+    const uint32_t lane_off = ncol * 4u;
+    const uint32_t ldb4 = ldb * 4u;
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
+    for (uint32_t b = bs; b < be; ++b) {
+        const uint32_t brow0 = blockColIdxs[b] * 16u;
+        const float *ablk = blocks + static_cast<size_t>(b) * 256u + c * 16u + g;
+        float a[4];
+        f32x4_t bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a[s] = ablk[4 * s];
+            bv[s] = buffer_load_vec<4>(rsrc, lane_off, (brow0 + 4 * s + g) * ldb4);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bv[s][t], acc[t], 0, 0, 0);
+        }
+    }
+    if (ncol < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4_t out{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            *reinterpret_cast<f32x4_t *>(C + static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol) = out;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- bsr_mfma_bf16
+// Same work split.  MFMA 16x16x32 bf16: lane (c, g) holds A[i = c][k = 8g .. 8g+7] and
+// B[k = 8g .. 8g+7][j = c].  k slots 0..15 are the 16 columns of block b, slots 16..31 those of
+// block b + 1 (zero when the block row has an odd block left).  A lane reads, for each of its 8 k
+// rows, the 4 consecutive bf16 of columns 4c .. 4c+3 (8 bytes, one per accumulator tile) and
+// regroups them per tile with v_perm_b32: the transpose B needs, done in registers.
+template <bool C_BF16>
+__global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
+                                                     const uint32_t *__restrict__ blockColIdxs,
+                                                     const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
+                                                     uint32_t N, uint32_t ldb, void *__restrict__ Cv, uint32_t ldc) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = blockIdx.x * 4 + wave;
+    if (item >= Mb * nST) return;
+    const uint32_t R = item / nST, st = item - R * nST;
+    const uint32_t c = lane & 15, g = lane >> 4;
+    const uint32_t ncol = st * 64 + c * 4;
+    const rsrc_t rsrc = make_rsrc(B, N * 2u);
+    const uint32_t lane_off = ncol * 2u;
+    const uint32_t ldb2 = ldb * 2u;
+    const uint32_t khalf = (g & 1) * 8u;  // first block column of this lane's 8 k slots
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
+    for (uint32_t b0 = bs; b0 < be; b0 += 2) {
+        const uint32_t b = b0 + (g >> 1);      // lanes g = 2,3 take the second block of the pair
+        const bool have = b < be;
+        const uint32_t bsafe = have ? b : b0;  // keep the index loads in range
+        const uint32_t brow0 = blockColIdxs[bsafe] * 16u + khalf;
+        u32x4_t araw = *reinterpret_cast<const u32x4_t *>(blocks + static_cast<size_t>(bsafe) * 256u + c * 16u + khalf);
+        if (!have) araw = u32x4_t{0u, 0u, 0u, 0u};
+        u32x2_t braw[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, have ? lane_off : kDropLoad, (brow0 + e) * ldb2, 0);
+            braw[e] = __builtin_bit_cast(u32x2_t, r);
+        }
+        const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, araw);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // tile t takes bf16 element t of every k row: dword t>>1, half t&1
+            u32x4_t packed;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t lo = braw[2 * p][t >> 1], hi = braw[2 * p + 1][t >> 1];
+                packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u)   // {hi.h1, lo.h1}
+                                    : __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, packed), acc[t], 0, 0, 0);
+        }
+    }
+    if (ncol < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t crow = static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol;
+            if constexpr (C_BF16) {
+                using bf2 = __bf16 __attribute__((ext_vector_type(2)));
+                u32x2_t o;
+                o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[0][r]), static_cast<__bf16>(acc[1][r])});
+                o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[2][r]), static_cast<__bf16>(acc[3][r])});
+                *reinterpret_cast<u32x2_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
+            } else {
+                const f32x4_t out{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                *reinterpret_cast<f32x4_t *>(static_cast<float *>(Cv) + crow) = out;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- dispatch
+struct BsrArgs {
+    hipStream_t stream;
+    uint32_t Mb, K, bR, bC;
+    const uint32_t *ptrs, *idxs;
+    const float *blocks, *B;
+    uint32_t N, ldb;
+    float *C;
+    uint32_t ldc;
+};
+
+template <int G, int VEC, class Acc>
+static void launch_valu(const BsrArgs &a) {
+    const uint32_t M = a.Mb * a.bR;
+    dim3 grid(ceil_div(M, 256 / G), ceil_div(a.N, G * VEC));
+    const uint64_t bytes = static_cast<uint64_t>(a.K) * a.ldb * 4u;
+    if (bytes > 0x7FFFFFFFull)
+        hipLaunchKernelGGL((bsr_valu<G, VEC, Acc, true>), grid, dim3(256), 0, a.stream, M, a.bR, a.bC, a.ptrs, a.idxs,
+                           a.blocks, a.B, 0u, a.N, a.ldb, a.C, a.ldc);
+    else
+        hipLaunchKernelGGL((bsr_valu<G, VEC, Acc, false>), grid, dim3(256), 0, a.stream, M, a.bR, a.bC, a.ptrs, a.idxs,
+                           a.blocks, a.B, static_cast<uint32_t>(bytes), a.N, a.ldb, a.C, a.ldc);
+}
+
+template <int VEC, class Acc>
+static void launch_valu_g(const BsrArgs &a, int g) {
+    switch (g) {
+        case 8: launch_valu<8, VEC, Acc>(a); break;
+        case 16: launch_valu<16, VEC, Acc>(a); break;
+        case 32: launch_valu<32, VEC, Acc>(a); break;
+        default: launch_valu<64, VEC, Acc>(a); break;
+    }
+}
+
+template <class Acc>
+static void launch_valu_v(const BsrArgs &a, int vec) {
+    const int g = pick_group(a.N, vec);
+    if (vec == 4) launch_valu_g<4, Acc>(a, g);
+    else if (vec == 2) launch_valu_g<2, Acc>(a, g);
+    else launch_valu_g<1, Acc>(a, g);
+}
+
+static bool mfma_shape_ok(uint32_t K, uint32_t N, uint32_t ldb, uint32_t ldc, const void *B, const void *C,
+                          const void *blocks, size_t elem) {
+    // whole 16-byte (fp32) / 8-byte (bf16) vectors of 4 columns; scalar offsets must fit 32 bits
+    return N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(blocks) &&
+           (reinterpret_cast<uintptr_t>(B) % (4 * elem) == 0) && (reinterpret_cast<uintptr_t>(C) % 8 == 0) &&
+           static_cast<uint64_t>(K) * ldb * elem <= 0xFFFFFFFFull;
+}
+
+}  // namespace mispmm
+
+using namespace mispmm;
+
+extern "C" int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t bR, uint32_t bC,
+                              uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,
+                              const float *blocks, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc,
+                              int kernel, int acc_mode) {
+    if (kernel < 0 || kernel > MISPMM_BSR_NUM_KERNELS) return fail(MISPMM_ERR_INVALID_ARG, "bsr: unknown kernel id %d", kernel);
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "bsr: unknown accumulate mode %d", acc_mode);
+    if (bR == 0 || bC == 0) return fail(MISPMM_ERR_INVALID_ARG, "bsr: zero block dimension");
+    if (numBlockRows == 0 || N == 0) return MISPMM_OK;
+    if (!blockRowPtrs) return fail(MISPMM_ERR_INVALID_ARG, "bsr: blockRowPtrs is null");
+    if (numBlocks != 0 && (!blockColIdxs || !blocks)) return fail(MISPMM_ERR_INVALID_ARG, "bsr: null block arrays");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    hipStream_t st = as_stream(stream);
+    const bool mfma_ok = bR == 16 && bC == 16 && aligned16(C) && mfma_shape_ok(K, N, ldb, ldc, B, C, blocks, 4);
+    if (kernel == 2 && !mfma_ok)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsr: MFMA kernel needs 16x16 blocks, N/ldb/ldc multiples of 4, 16-byte aligned operands");
+    if (kernel == 2 && acc_mode == MISPMM_ACC_REFERENCE)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsr: the MFMA kernel has FAST (fused) numerics only");
+    if (kernel == MISPMM_KERNEL_AUTO) kernel = (mfma_ok && acc_mode == MISPMM_ACC_FAST) ? 2 : 1;
+    if (kernel == 2) {
+        const uint32_t nST = ceil_div(N, 64u);
+        hipLaunchKernelGGL(bsr_mfma_f32, dim3(ceil_div(numBlockRows * nST, 4u)), dim3(256), 0, st, numBlockRows, nST,
+                           blockRowPtrs, blockColIdxs, blocks, B, N, ldb, C, ldc);
+    } else {
+        const BsrArgs a{st, numBlockRows, K, bR, bC, blockRowPtrs, blockColIdxs, blocks, B, N, ldb, C, ldc};
+        const int vec = pick_vec(B, ldb, C, ldc, N);
+        if (acc_mode == MISPMM_ACC_REFERENCE) launch_valu_v<AccRefF32>(a, vec);
+        else launch_valu_v<AccFast>(a, vec);
+    }
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t bR, uint32_t bC,
+                               uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,
+                               const uint16_t *blocks, const uint16_t *B, uint32_t N, uint32_t ldb, void *C,
+                               uint32_t ldc, int c_bf16) {
+    if (bR != 16 || bC != 16) return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: only 16x16 blocks (got %ux%u)", bR, bC);
+    if (numBlockRows == 0 || N == 0) return MISPMM_OK;
+    if (!blockRowPtrs || !B || !C) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: null pointer");
+    if (numBlocks != 0 && (!blockColIdxs || !blocks)) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: null block arrays");
+    if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: leading dimension smaller than N");
+    if (!mfma_shape_ok(K, N, ldb, ldc, B, C, blocks, 2) || (!c_bf16 && !aligned16(C)))
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: N/ldb/ldc must be multiples of 4 and operands vector-aligned");
+    const uint32_t nST = ceil_div(N, 64u);
+    dim3 grid(ceil_div(numBlockRows * nST, 4u));
+    if (c_bf16)
+        hipLaunchKernelGGL(bsr_mfma_bf16<true>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
+                           blockColIdxs, blocks, B, N, ldb, C, ldc);
+    else
+        hipLaunchKernelGGL(bsr_mfma_bf16<false>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
+                           blockColIdxs, blocks, B, N, ldb, C, ldc);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}

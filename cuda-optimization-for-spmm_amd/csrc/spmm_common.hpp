@@ -1,0 +1,114 @@
+// Device-side building blocks shared by the CSR / ELL / BSR / COO kernels.
+// gfx950 only: wave = 64 lanes, 16-byte global accesses, no CUDA-isms.
+#pragma once
+#include "mispmm_internal.hpp"
+
+namespace mispmm {
+
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct VecOf;
+template <> struct VecOf<1> { using type = float; };
+template <> struct VecOf<2> { using type = f32x2; };
+template <> struct VecOf<4> { using type = f32x4; };
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::type load_vec(const float *p) {
+    return *reinterpret_cast<const typename VecOf<VEC>::type *>(p);
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, typename VecOf<VEC>::type v) {
+    *reinterpret_cast<typename VecOf<VEC>::type *>(p) = v;
+}
+template <int VEC>
+__device__ __forceinline__ float vec_get(const typename VecOf<VEC>::type &v, int i) {
+    if constexpr (VEC == 1) return v; else return v[i];
+}
+template <int VEC>
+__device__ __forceinline__ void vec_set(typename VecOf<VEC>::type &v, int i, float x) {
+    if constexpr (VEC == 1) v = x; else v[i] = x;
+}
+
+// ---- bounds-checked buffer loads --------------------------------------------------------------
+// B is read through a raw buffer descriptor: `voffset` (per lane) is range-checked against the
+// descriptor's byte count, `soffset` (wave-uniform SGPR) is not.  A load whose voffset has bit 31
+// set is out of range: the hardware returns zeros and fetches nothing, which is how the kernels
+// drop the unused slots of a fixed-size load batch without branching around a load (a branch
+// there makes hipcc drain vmcnt before the next load and serialises the gather).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t kDropLoad = 0x80000000u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), /*stride*/ 0, static_cast<int>(bytes),
+                                             0x00020000);
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::type buffer_load_vec(rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
+    if constexpr (VEC == 1) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+    } else if constexpr (VEC == 2) {
+        auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, 0);
+        return __builtin_bit_cast(f32x2, r);
+    } else {
+        auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+        return __builtin_bit_cast(f32x4, r);
+    }
+}
+
+// ---- accumulation policies (mispmm.h: enum mispmm_acc_mode) -----------------------------------
+// This library is compiled with -ffp-contract=off, so `a * b` followed by `+` stays two
+// roundings exactly as written; the fused form is spelled __builtin_fmaf.
+
+// Reference CSR: fp32 product, double running sum, one final rounding
+// (/root/reference/src/spmm/csr/spmm_csr.cpp:20-25 with AccT = double).
+struct AccRefWide {
+    using T = double;
+    static __device__ __forceinline__ void mac(T &acc, float a, float b) {
+        float p = a * b;
+        acc += static_cast<double>(p);
+    }
+    static __device__ __forceinline__ float finish(T acc) { return static_cast<float>(acc); }
+};
+
+// Reference COO / ELL / BSR: fp32 product then fp32 add (e.g. spmm_ell.cpp:25).
+struct AccRefF32 {
+    using T = float;
+    static __device__ __forceinline__ void mac(T &acc, float a, float b) {
+        float p = a * b;
+        acc = acc + p;
+    }
+    static __device__ __forceinline__ float finish(T acc) { return acc; }
+};
+
+// Fast: one fused multiply-add per term.
+struct AccFast {
+    using T = float;
+    static __device__ __forceinline__ void mac(T &acc, float a, float b) { acc = __builtin_fmaf(a, b, acc); }
+    static __device__ __forceinline__ float finish(T acc) { return acc; }
+};
+
+// Widest vector width usable for row-major dense operands B (ldb) and C (ldc) with N columns.
+inline int pick_vec(const float *B, uint32_t ldb, const float *C, uint32_t ldc, uint32_t N) {
+    if (N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) return 4;
+    if (N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && aligned8(B) && aligned8(C)) return 2;
+    return 1;
+}
+
+// Lanes per row group for the grouped kernels: the smallest power of two in [8, 64] whose
+// G * VEC covers N (64 when even a full wave does not).
+inline int pick_group(uint32_t N, int vec) {
+    uint32_t need = ceil_div(N, static_cast<uint32_t>(vec));
+    int g = 8;
+    while (g < 64 && static_cast<uint32_t>(g) < need) g <<= 1;
+    return g;
+}
+
+inline int check_dense_args(const float *B, uint32_t N, uint32_t ldb, const float *C, uint32_t ldc) {
+    if (!B || !C) return fail(MISPMM_ERR_INVALID_ARG, "B or C is null");
+    if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "leading dimension smaller than N (N=%u ldb=%u ldc=%u)", N, ldb, ldc);
+    return MISPMM_OK;
+}
+
+}  // namespace mispmm

@@ -1,0 +1,433 @@
+// CSR x dense SpMM for gfx950.  C[M x N] = A * B, row-major B/C, fp32 values, u32 indices.
+//
+// The path this replaces: /root/reference/src/spmm/csr/spmm_csr_k{1,2,3,4}.cu (kernels and
+// wrapper bodies).  Nothing here is derived from those kernels: the work split is by 64-lane
+// wavefronts that own whole C rows (or 2^k rows when N is narrow), each lane owning VEC
+// contiguous output columns so every B-row read is one coalesced 256 B..1 KiB segment; a row's
+// products are summed in CSR storage order inside one lane, so there is no cross-lane reduction,
+// no atomics, and the result can reproduce the reference CPU engine's rounding bit for bit
+// (AccRefWide).  Kernels differ only in how the row's (col, val) pairs reach the lanes:
+//   k1  vector loads + lane shuffle broadcast (any row length, rows share a wave when N <= 128)
+//   k2  a workgroup's contiguous (col, val) range staged through LDS, read back as broadcasts
+//   k3  one wave per row: one coalesced vector load per 64 (col, val) pairs, v_readlane moves each
+//       pair to SGPRs, so the B row base is an SGPR pair and each B read a saddr-form global_load
+//   k4  k3 with two rows interleaved per wave (half the waves, twice the loads in flight)
+// Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
+//   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
+#include "spmm_common.hpp"
+
+namespace mispmm {
+
+// Every kernel follows one rule learnt from the ISA: the B reads of a batch are issued back to
+// back with no branch between them (unused slots are dropped by the buffer range check, see
+// spmm_common.hpp), a sched_barrier keeps hipcc from interleaving consumption into the batch, and
+// only the arithmetic is predicated.
+
+// ---------------------------------------------------------------------------------- wide fallback
+// 64-bit addressing, for a B that spans 4 GiB or more (buffer offsets are 32-bit).  Same work
+// split as k1; the unused slots of a batch re-read the row's last entry instead of being dropped.
+template <int G, int VEC, class Acc>
+__global__ __launch_bounds__(256) void csr_wide(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                                const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                                const float *__restrict__ B, uint32_t N, uint32_t ldb,
+                                                float *__restrict__ C, uint32_t ldc) {
+    constexpr int GROUPS = 256 / G;
+    constexpr int U = (VEC == 4) ? 4 : 8;
+    using vec_t = typename VecOf<VEC>::type;
+    const uint32_t lane = threadIdx.x % G;
+    const uint32_t row = blockIdx.x * GROUPS + threadIdx.x / G;
+    const uint32_t col0 = blockIdx.y * (G * VEC) + lane * VEC;
+    const bool row_ok = row < M;
+    const bool col_ok = col0 < N;
+    uint32_t start = 0, end = 0;
+    if (row_ok) {
+        start = rowPtrs[row];
+        end = rowPtrs[row + 1];
+    }
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const float *bcol = B + (col_ok ? col0 : 0);  // idle lanes re-read column 0: valid, never stored
+
+    for (uint32_t base = start; base < end; base += G) {
+        const uint32_t cnt = min(static_cast<uint32_t>(G), end - base);
+        const uint32_t mine = base + min(lane, cnt - 1);
+        const uint32_t my_col = colIdxs[mine];
+        const float my_val = vals[mine];
+        for (uint32_t j = 0; j < cnt; j += U) {
+            vec_t bv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t src = min(j + u, cnt - 1);
+                const uint32_t c = __shfl(my_col, src, G);
+                av[u] = __shfl(my_val, src, G);
+                bv[u] = load_vec<VEC>(bcol + static_cast<size_t>(c) * ldb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < cnt) {  // re-read slots hold real B values: they must be skipped, not zeroed
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
+                }
+            }
+        }
+    }
+    if (row_ok && col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ k1
+// 256/G rows per workgroup, G lanes per row.  Lane i of a row group loads pair i of the current
+// G-pair chunk and turns its column into a byte offset (one multiply per pair, spread
+// over the lanes); the offsets are then broadcast with lane shuffles.
+template <int G, int VEC, class Acc>
+__global__ __launch_bounds__(256) void csr_k1(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                              const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                              const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                              float *__restrict__ C, uint32_t ldc) {
+    constexpr int GROUPS = 256 / G;
+    constexpr int U = (VEC == 4) ? 8 : 16;  // B loads in flight per lane
+    using vec_t = typename VecOf<VEC>::type;
+    const uint32_t lane = threadIdx.x % G;
+    const uint32_t row = blockIdx.x * GROUPS + threadIdx.x / G;
+    const uint32_t col0 = blockIdx.y * (G * VEC) + lane * VEC;
+    const bool row_ok = row < M;
+    const bool col_ok = col0 < N;
+    uint32_t start = 0, end = 0;
+    if (row_ok) {
+        start = rowPtrs[row];
+        end = rowPtrs[row + 1];
+    }
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;  // lanes past N never fetch
+
+    for (uint32_t base = start; base < end; base += G) {
+        const uint32_t cnt = min(static_cast<uint32_t>(G), end - base);
+        const uint32_t mine = base + min(lane, cnt - 1);
+        const uint32_t my_off = colIdxs[mine] * (ldb * 4u);
+        const float my_val = vals[mine];
+        for (uint32_t j = 0; j < cnt; j += U) {
+            vec_t bv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t src = (j + u) & (G - 1);
+                const uint32_t off = __shfl(my_off, src, G);
+                const float a = __shfl(my_val, src, G);
+                av[u] = (j + u < cnt) ? a : 0.f;
+                bv[u] = buffer_load_vec<VEC>(rsrc, (j + u < cnt) ? off + lane_off : kDropLoad, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // dropped slots contribute 0 * 0 (header comment)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
+            }
+        }
+    }
+    if (row_ok && col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ k2
+// One workgroup = 256/G consecutive rows.  Their (col, val) pairs are one contiguous range of the
+// CSR arrays: all 256 threads copy it into LDS with coalesced loads (chunks of CHUNK pairs, the
+// column already scaled to a byte offset), then each row group walks its own sub-range with
+// broadcast LDS reads.
+template <int G, int VEC, class Acc>
+__global__ __launch_bounds__(256) void csr_k2(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                              const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                              const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                              float *__restrict__ C, uint32_t ldc) {
+    constexpr int GROUPS = 256 / G;
+    constexpr int CHUNK = 1024;
+    constexpr int U = (VEC == 4) ? 8 : 16;
+    using vec_t = typename VecOf<VEC>::type;
+    __shared__ uint2 stage[CHUNK];  // {B byte offset of the column, val bits}
+
+    const uint32_t lane = threadIdx.x % G;
+    const uint32_t row0 = blockIdx.x * GROUPS;
+    const uint32_t row = row0 + threadIdx.x / G;
+    const uint32_t col0 = blockIdx.y * (G * VEC) + lane * VEC;
+    const bool row_ok = row < M;
+    const bool col_ok = col0 < N;
+    const uint32_t row_last = min(row0 + GROUPS, M);
+    const uint32_t blk_start = rowPtrs[row0];  // row0 < M by grid construction
+    const uint32_t blk_end = rowPtrs[row_last];
+    uint32_t start = 0, end = 0;
+    if (row_ok) {
+        start = rowPtrs[row];
+        end = rowPtrs[row + 1];
+    }
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;
+
+    for (uint32_t lo = blk_start; lo < blk_end; lo += CHUNK) {
+        const uint32_t hi = min(lo + CHUNK, blk_end);
+        if (lo != blk_start) __syncthreads();  // previous chunk fully consumed
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            stage[i - lo] = make_uint2(colIdxs[i] * (ldb * 4u), __float_as_uint(vals[i]));
+        }
+        __syncthreads();
+        const uint32_t s = max(start, lo), e = min(end, hi);
+        for (uint32_t j = s; j < e; j += U) {
+            vec_t bv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint2 cv = stage[(j + u - lo) & (CHUNK - 1)];
+                av[u] = (j + u < e) ? __uint_as_float(cv.y) : 0.f;
+                bv[u] = buffer_load_vec<VEC>(rsrc, (j + u < e) ? cv.x + lane_off : kDropLoad, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
+            }
+        }
+    }
+    if (row_ok && col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
+// ------------------------------------------------------------------------------------- k3 / k4
+// Wave-per-row.  The wave's row is provably uniform (readfirstlane), so rowPtrs come by s_load.
+// A chunk of up to 64 (col, val) pairs is fetched by ONE coalesced vector load per array (lane i
+// holds pair i; the next chunk is prefetched while this one is consumed).  v_readlane moves each
+// column to an SGPR, scaled to the byte offset of that B row, which rides in the buffer load's
+// scalar offset: `buffer_load_dwordxN v, v_lane_off, s[rsrc], s_row_off offen`.  The descriptor
+// spans one row's N*4 bytes, so lanes past N (and the unused slots of the last batch, via
+// kDropLoad) fetch nothing.  B reads go out 16 per lane per row; ROWS rows are interleaved per
+// wave (k4 = 2) to halve the wave count and double the loads in flight.
+// One batch: U B-row reads per row issued back to back, then U multiply-adds per row in storage
+// order.  Slots at or past the row's count are dropped loads (zeros) times a zeroed coefficient:
+// 0 * 0 = +0 added to an accumulator that started at +0 and therefore is never -0, an exact no-op
+// in both accumulate modes.
+template <int VEC, int ROWS, int U, class Acc>
+__device__ __forceinline__ void wave_batch(rsrc_t rsrc, uint32_t lane_off, uint32_t ldb4, const uint32_t (&cur_col)[ROWS],
+                                           const float (&cur_val)[ROWS], const uint32_t (&cnt)[ROWS], uint32_t j,
+                                           typename Acc::T (&acc)[ROWS][VEC]) {
+    typename VecOf<VEC>::type bv[ROWS][U];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const uint32_t c = __builtin_amdgcn_readlane(cur_col[r], (j + t) & 63);
+            bv[r][t] = buffer_load_vec<VEC>(rsrc, (j + t < cnt[r]) ? lane_off : kDropLoad, c * ldb4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const float a0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cur_val[r]), (j + t) & 63));
+            const float a = (j + t < cnt[r]) ? a0 : 0.f;  // scalar select, wave-uniform
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) Acc::mac(acc[r][v], a, vec_get<VEC>(bv[r][t], v));
+        }
+    }
+}
+
+template <int VEC, int ROWS, class Acc>
+__global__ __launch_bounds__(256) void csr_k3(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                              const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                              const float *__restrict__ B, uint32_t N, uint32_t ldb,
+                                              float *__restrict__ C, uint32_t ldc) {
+    using vec_t = typename VecOf<VEC>::type;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row0 = (blockIdx.x * 4 + wave) * ROWS;
+    if (row0 >= M) return;  // wave-uniform exit
+    const uint32_t col0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    const bool col_ok = col0 < N;
+    const rsrc_t rsrc = make_rsrc(B, N * 4u);
+    const uint32_t lane_off = col0 * 4u;  // >= N*4 for lanes past N: dropped by the range check
+    const uint32_t ldb4 = ldb * 4u;
+
+    uint32_t pos[ROWS], end[ROWS];
+    uint32_t cur_col[ROWS];
+    float cur_val[ROWS];
+    typename Acc::T acc[ROWS][VEC];
+    bool more = false;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const bool ok = row0 + r < M;
+        pos[r] = ok ? rowPtrs[row0 + r] : 0;
+        end[r] = ok ? rowPtrs[row0 + r + 1] : 0;
+        more |= pos[r] < end[r];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[r][v] = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        cur_col[r] = 0;
+        cur_val[r] = 0.f;
+        if (pos[r] < end[r]) {  // wave-uniform; the clamp keeps every lane's index inside the row
+            const uint32_t i = min(pos[r] + lane, end[r] - 1);
+            cur_col[r] = colIdxs[i];
+            cur_val[r] = vals[i];
+        }
+    }
+    while (more) {
+        uint32_t nxt_col[ROWS];
+        float nxt_val[ROWS];
+        uint32_t cnt[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {  // prefetch the next chunk of (col, val)
+            nxt_col[r] = 0;
+            nxt_val[r] = 0.f;
+            if (pos[r] + 64 < end[r]) {
+                const uint32_t i = min(pos[r] + 64 + lane, end[r] - 1);
+                nxt_col[r] = colIdxs[i];
+                nxt_val[r] = vals[i];
+            }
+            cnt[r] = min(64u, end[r] - pos[r]);
+        }
+        uint32_t maxcnt = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) maxcnt = max(maxcnt, cnt[r]);
+        for (uint32_t j = 0; j < maxcnt;) {  // wave-uniform: whole batches sit under the branches
+            const uint32_t rem = maxcnt - j;
+            if (rem > 8) {
+                wave_batch<VEC, ROWS, 16, Acc>(rsrc, lane_off, ldb4, cur_col, cur_val, cnt, j, acc);
+                j += 16;
+            } else if (rem > 4) {
+                wave_batch<VEC, ROWS, 8, Acc>(rsrc, lane_off, ldb4, cur_col, cur_val, cnt, j, acc);
+                j += 8;
+            } else {
+                wave_batch<VEC, ROWS, 4, Acc>(rsrc, lane_off, ldb4, cur_col, cur_val, cnt, j, acc);
+                j += 4;
+            }
+        }
+        more = false;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            pos[r] = min(pos[r] + 64, end[r]);
+            cur_col[r] = nxt_col[r];
+            cur_val[r] = nxt_val[r];
+            more |= pos[r] < end[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r < M && col_ok) {
+            vec_t out;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[r][v]));
+            store_vec<VEC>(C + static_cast<size_t>(row0 + r) * ldc + col0, out);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+struct CsrArgs {
+    hipStream_t stream;
+    uint32_t M, K;
+    const uint32_t *rowPtrs, *colIdxs;
+    const float *vals, *B;
+    uint32_t N, ldb;
+    float *C;
+    uint32_t ldc;
+};
+
+template <int G, int VEC, class Acc>
+static void launch_grouped(const CsrArgs &a, int kernel, bool wide) {
+    dim3 grid(ceil_div(a.M, 256 / G), ceil_div(a.N, G * VEC));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    if (wide)
+        hipLaunchKernelGGL((csr_wide<G, VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals,
+                           a.B, a.N, a.ldb, a.C, a.ldc);
+    else if (kernel == 1)
+        hipLaunchKernelGGL((csr_k1<G, VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
+                           b_bytes, a.N, a.ldb, a.C, a.ldc);
+    else
+        hipLaunchKernelGGL((csr_k2<G, VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
+                           b_bytes, a.N, a.ldb, a.C, a.ldc);
+}
+
+template <int VEC, class Acc>
+static void launch_grouped_g(const CsrArgs &a, int kernel, int g, bool wide) {
+    switch (g) {
+        case 8: launch_grouped<8, VEC, Acc>(a, kernel, wide); break;
+        case 16: launch_grouped<16, VEC, Acc>(a, kernel, wide); break;
+        case 32: launch_grouped<32, VEC, Acc>(a, kernel, wide); break;
+        default: launch_grouped<64, VEC, Acc>(a, kernel, wide); break;
+    }
+}
+
+template <int VEC, int ROWS, class Acc>
+static void launch_wave(const CsrArgs &a) {
+    dim3 grid(ceil_div(a.M, 4 * ROWS), ceil_div(a.N, 64 * VEC));
+    hipLaunchKernelGGL((csr_k3<VEC, ROWS, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
+                       a.N, a.ldb, a.C, a.ldc);
+}
+
+template <class Acc>
+static void launch_csr(const CsrArgs &a, int kernel, int vec) {
+    // buffer offsets are 32-bit and bit 31 marks a dropped load: a B of 2 GiB or more takes the
+    // 64-bit-address kernel
+    const bool wide = static_cast<uint64_t>(a.K) * a.ldb * 4u > 0x7FFFFFFFull;
+    if (kernel == 1 || kernel == 2 || wide) {
+        const int g = pick_group(a.N, vec);
+        if (vec == 4) launch_grouped_g<4, Acc>(a, kernel, g, wide);
+        else if (vec == 2) launch_grouped_g<2, Acc>(a, kernel, g, wide);
+        else launch_grouped_g<1, Acc>(a, kernel, g, wide);
+        return;
+    }
+    // wave per row: narrow the vector so a 64-lane wave is not mostly idle at small N
+    while (vec > 1 && 64u * (vec / 2) >= a.N) vec /= 2;
+    if (kernel == 3) {
+        if (vec == 4) launch_wave<4, 1, Acc>(a);
+        else if (vec == 2) launch_wave<2, 1, Acc>(a);
+        else launch_wave<1, 1, Acc>(a);
+    } else {
+        if (vec == 4) launch_wave<4, 2, Acc>(a);
+        else if (vec == 2) launch_wave<2, 2, Acc>(a);
+        else launch_wave<1, 2, Acc>(a);
+    }
+}
+
+}  // namespace mispmm
+
+using namespace mispmm;
+
+extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                              const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
+                              float *C, uint32_t ldc, int kernel, int acc_mode) {
+    if (kernel < 0 || kernel > MISPMM_CSR_NUM_KERNELS) return fail(MISPMM_ERR_INVALID_ARG, "csr: unknown kernel id %d", kernel);
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!rowPtrs) return fail(MISPMM_ERR_INVALID_ARG, "csr: rowPtrs is null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (kernel == MISPMM_KERNEL_AUTO) kernel = 1;
+    const CsrArgs a{as_stream(stream), M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc};
+    const int vec = pick_vec(B, ldb, C, ldc, N);
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_csr<AccRefWide>(a, kernel, vec);
+    else launch_csr<AccFast>(a, kernel, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}

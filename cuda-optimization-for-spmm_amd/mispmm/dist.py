@@ -1,0 +1,137 @@
+"""Row-sharded SpMM across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+New capability: the reference is single-GPU (`cudaSetDevice(7)`, src/main.cu:176).  Rows of A --
+hence rows of C -- are independent, so A is cut into `world` contiguous row ranges of near-equal
+nnz (mispmm_shard_rows_by_nnz_host), B is replicated once by broadcast, every rank multiplies its
+slab with the single-GPU kernel, and the only exchange is the gather of C row slabs.  Slabs are
+padded to the tallest slab so one `all_gather_into_tensor` moves a whole bucket of steps; the
+collective runs on its own stream and overlaps the next bucket's kernels (xGMI is point to point:
+few, large messages).
+
+The compute step is injectable so the partition / bucket / gather logic is exercised on CPU with
+the gloo backend (tests/test_dist_cpu.py); on a GPU the default is the HIP kernel via the C ABI.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import formats, ops
+
+
+def shard_bounds(row_ptrs, parts):
+    return ops.shard_rows_by_nnz(row_ptrs, parts).astype(np.int64)
+
+
+def csr_row_slice(csr, r0, r1):
+    """Rows [r0, r1) of a CSR as a stand-alone CSR (row pointers rebased, columns untouched)."""
+    s, e = int(csr.row_ptrs[r0]), int(csr.row_ptrs[r1])
+    ptrs = (csr.row_ptrs[r0:r1 + 1].astype(np.int64) - s).astype(np.uint32)
+    return formats.CSR(r1 - r0, csr.num_cols, ptrs, csr.col_idxs[s:e].copy(), csr.data[s:e].copy())
+
+
+class ShardedCsrSpmm:
+    def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.n = int(n_cols)
+        self.kernel, self.acc = kernel, acc
+        self.bucket = max(1, int(bucket))
+        self.num_rows, self.num_cols = csr.num_rows, csr.num_cols
+        self.bounds = shard_bounds(csr.row_ptrs, self.world)
+        self.r0, self.r1 = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.rows = self.r1 - self.r0
+        self.slab_rows = max(1, int(np.diff(self.bounds).max()))
+        local = csr_row_slice(csr, self.r0, self.r1)
+        self.local_nnz = local.nnz
+        self.a = ops.DeviceCSR.from_host(local, device=self.device)
+        self.b = torch.zeros((self.num_cols, self.n), dtype=torch.float32, device=self.device)
+        # two bucket-sized slab rings and gather targets: one being filled, one being gathered
+        self.ring = [torch.zeros((self.bucket, self.slab_rows, self.n), dtype=torch.float32, device=self.device)
+                     for _ in range(2)]
+        self.gathered = [torch.zeros((self.world, self.bucket, self.slab_rows, self.n), dtype=torch.float32,
+                                     device=self.device) for _ in range(2)]
+        self.pending = [None, None]
+        self.step_count = 0
+        self.last = None   # (buffer index, slot) of the most recent gathered step
+        self.compute = compute if compute is not None else self._hip_compute
+        if self.on_gpu:
+            self.compute_stream = torch.cuda.Stream(device=self.device)
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        else:
+            self.compute_stream = self.comm_stream = None
+
+    # -- the compute step ------------------------------------------------------------------------
+    def _hip_compute(self, a, b, out):
+        ops.spmm_csr(a, b, out=out, kernel=self.kernel, acc=self.acc, stream=self.compute_stream)
+
+    # -- one-time B replication ------------------------------------------------------------------
+    def broadcast_b(self, b_host):
+        if self.rank == 0:
+            self.b.copy_(torch.from_numpy(np.ascontiguousarray(b_host, dtype=np.float32)))
+        dist.broadcast(self.b, src=0)
+        if self.on_gpu:
+            torch.cuda.synchronize(self.device)
+
+    # -- steady state ----------------------------------------------------------------------------
+    def _gather(self, buf):
+        if self.on_gpu:
+            done = torch.cuda.Event()
+            done.record(self.compute_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(done)
+                self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf], self.ring[buf], async_op=True)
+        else:
+            self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf], self.ring[buf], async_op=True)
+
+    def _wait(self, buf, on_stream=None):
+        w = self.pending[buf]
+        if w is None:
+            return
+        if self.on_gpu and on_stream is not None:
+            with torch.cuda.stream(on_stream):
+                w.wait()
+        else:
+            w.wait()
+        self.pending[buf] = None
+
+    def run(self, steps, gather=True):
+        for _ in range(steps):
+            i = self.step_count
+            buf, slot = (i // self.bucket) % 2, i % self.bucket
+            if slot == 0:
+                self._wait(buf, self.compute_stream)      # the gather that last read this ring is done
+            if self.rows:
+                self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
+            self.step_count += 1
+            if gather and slot == self.bucket - 1:
+                self._gather(buf)
+                self.last = (buf, slot)
+
+    def finish(self, gather=True):
+        """Gather a partially filled bucket and wait for every collective in flight."""
+        i = self.step_count
+        if gather and i % self.bucket:
+            buf = (i // self.bucket) % 2
+            self._gather(buf)
+            self.last = (buf, (i - 1) % self.bucket)
+            self.step_count = (i // self.bucket + 1) * self.bucket     # next run starts a fresh bucket
+        for buf in (0, 1):
+            self._wait(buf, self.comm_stream)
+        if self.on_gpu:
+            self.compute_stream.synchronize()
+            self.comm_stream.synchronize()
+
+    # -- results ---------------------------------------------------------------------------------
+    def gathered_c(self):
+        """Full C [num_rows, n] of the most recent gathered step (every rank holds it)."""
+        if self.last is None:
+            raise RuntimeError("no gathered step yet")
+        buf, slot = self.last
+        parts = [self.gathered[buf][r, slot, :int(self.bounds[r + 1] - self.bounds[r])] for r in range(self.world)]
+        return torch.cat(parts, dim=0)
+
+    def local_slab(self, slot=None):
+        i = self.step_count - 1
+        buf, s = (i // self.bucket) % 2, (i % self.bucket if slot is None else slot)
+        return self.ring[buf][s, :self.rows]

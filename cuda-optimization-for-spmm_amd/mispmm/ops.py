@@ -1,0 +1,228 @@
+"""SpMM entry points on torch tensors: thin plumbing from torch device memory and
+streams to the C ABI (data_ptr() in, data_ptr() out).  PyTorch is used for
+allocation and stream handles only -- all arithmetic happens in libmispmm.so."""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import capi, formats
+
+
+def _stream_ptr(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _dev_u32(a, device):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return torch.from_numpy(a.view(np.int32).copy()).to(device)
+
+
+def _dev_f32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() else 0)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise ValueError("mispmm ops take device tensors; there is no CPU path")
+
+
+def _dense_ld(t):
+    if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1 and t.shape[1] > 1:
+        raise ValueError("dense operands must be 2-D float32 with unit column stride")
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+@dataclass
+class DeviceCSR:
+    num_rows: int
+    num_cols: int
+    nnz: int
+    row_ptrs: torch.Tensor
+    col_idxs: torch.Tensor
+    data: torch.Tensor
+
+    @staticmethod
+    def from_host(csr, device="cuda"):
+        return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
+                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device))
+
+
+@dataclass
+class DeviceELL:
+    num_rows: int
+    num_cols: int
+    width: int
+    col_idxs: torch.Tensor
+    data: torch.Tensor
+
+    @staticmethod
+    def from_host(ell, device="cuda"):
+        if isinstance(ell, formats.ELLColMajor):
+            ell = colmajor_ell_to_rowmajor(ell)
+        return DeviceELL(ell.num_rows, ell.num_cols, ell.width, _dev_u32(ell.col_idxs, device),
+                         _dev_f32(ell.data, device))
+
+
+@dataclass
+class DeviceBSR:
+    num_rows: int
+    num_cols: int
+    block_row_size: int
+    block_col_size: int
+    num_blocks: int
+    block_row_ptrs: torch.Tensor
+    block_col_idxs: torch.Tensor
+    data: torch.Tensor       # float32 blocks, or int16-viewed bf16 bit patterns
+
+    @staticmethod
+    def from_host(bsr, device="cuda"):
+        return DeviceBSR(bsr.num_rows, bsr.num_cols, bsr.block_row_size, bsr.block_col_size, bsr.num_blocks,
+                         _dev_u32(bsr.block_row_ptrs, device), _dev_u32(bsr.block_col_idxs, device),
+                         _dev_f32(bsr.data.reshape(-1), device))
+
+
+@dataclass
+class DeviceCOO:
+    num_rows: int
+    num_cols: int
+    nnz: int
+    row_idxs: torch.Tensor
+    col_idxs: torch.Tensor
+    data: torch.Tensor
+
+    @staticmethod
+    def from_host(coo, device="cuda"):
+        order = np.lexsort((coo.col_idxs, coo.row_idxs))
+        return DeviceCOO(coo.num_rows, coo.num_cols, coo.nnz, _dev_u32(coo.row_idxs[order], device),
+                         _dev_u32(coo.col_idxs[order], device), _dev_f32(coo.data[order], device))
+
+
+def _out(m, n, b, out):
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=b.device)
+    _require_gpu(out)
+    if out.shape != (m, n):
+        raise ValueError(f"out has shape {tuple(out.shape)}, expected {(m, n)}")
+    return out
+
+
+def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None):
+    """C = A @ B.  a: DeviceCSR, b: [K, N] float32 device tensor (row-major, any row stride)."""
+    _require_gpu(a.row_ptrs, b)
+    if b.shape[0] != a.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    n = b.shape[1]
+    c = _out(a.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_csr_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs),
+                                         _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
+                                         int(kernel), capi.ACC_MODES[acc]))
+    return c
+
+
+def spmm_ell(a, b, out=None, kernel=0, acc="reference", stream=None):
+    _require_gpu(a.col_idxs, b)
+    if b.shape[0] != a.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    n = b.shape[1]
+    c = _out(a.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_ell_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.width, _p(a.col_idxs),
+                                         _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c), int(kernel),
+                                         capi.ACC_MODES[acc]))
+    return c
+
+
+def spmm_bsr(a, b, out=None, kernel=0, acc="reference", stream=None):
+    _require_gpu(a.block_row_ptrs, b)
+    if b.shape[0] != a.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    n = b.shape[1]
+    c = _out(a.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_bsr_f32(_stream_ptr(stream), a.num_rows // a.block_row_size, a.num_cols,
+                                         a.block_row_size, a.block_col_size, a.num_blocks, _p(a.block_row_ptrs),
+                                         _p(a.block_col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
+                                         int(kernel), capi.ACC_MODES[acc]))
+    return c
+
+
+def spmm_coo(a, b, out=None, kernel=0, acc="reference", stream=None, workspace=True):
+    """workspace=True allocates the (M+1)-entry row-boundary scratch; False uses binary search."""
+    _require_gpu(a.row_idxs, b)
+    ws = torch.empty(a.num_rows + 1, dtype=torch.int32, device=b.device) if workspace else None
+    if b.shape[0] != a.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    n = b.shape[1]
+    c = _out(a.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_coo_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_idxs),
+                                         _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
+                                         _p(ws), int(kernel), capi.ACC_MODES[acc]))
+    return c
+
+
+def f32_to_bf16(x, stream=None):
+    """Device fp32 tensor -> int16 tensor of bf16 bit patterns (round to nearest even)."""
+    _require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    capi.check(capi.lib().mispmm_f32_to_bf16(_stream_ptr(stream), x.numel(), _p(x), _p(out)))
+    return out
+
+
+def bf16_to_f32(x, stream=None):
+    _require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().mispmm_bf16_to_f32(_stream_ptr(stream), x.numel(), _p(x), _p(out)))
+    return out
+
+
+def spmm_bsr_bf16(a, blocks_bf16, b_bf16, out_bf16=False, out=None, stream=None):
+    """a: DeviceBSR (index arrays used), blocks_bf16 / b_bf16: int16 tensors of bf16 bits."""
+    _require_gpu(blocks_bf16, b_bf16)
+    n = b_bf16.shape[1]
+    if out is None:
+        out = torch.empty((a.num_rows, n), dtype=torch.int16 if out_bf16 else torch.float32, device=b_bf16.device)
+    capi.check(capi.lib().mispmm_bsr_bf16(_stream_ptr(stream), a.num_rows // a.block_row_size, a.num_cols,
+                                          a.block_row_size, a.block_col_size, a.num_blocks, _p(a.block_row_ptrs),
+                                          _p(a.block_col_idxs), _p(blocks_bf16), _p(b_bf16), n, b_bf16.stride(0),
+                                          _p(out), out.stride(0), int(bool(out_bf16))))
+    return out
+
+
+def dense_transpose(x, stream=None):
+    _require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().mispmm_dense_transpose_f32(_stream_ptr(stream), x.shape[0], x.shape[1], _p(x), _p(out)))
+    return out
+
+
+def colmajor_ell_to_rowmajor(ell):
+    """Host conversion through the library's own helper (the path the C++ host uses)."""
+    ridx = np.ascontiguousarray(ell.row_idxs, dtype=np.uint32)
+    vals = np.ascontiguousarray(ell.data, dtype=np.float32)
+    width = ctypes.c_uint32(0)
+    l = capi.lib()
+    capi.check(l.mispmm_ell_colmajor_to_rowmajor_host(ell.num_rows, ell.num_cols, ell.max_col_nnz, ridx.ctypes.data,
+                                                      vals.ctypes.data, ctypes.byref(width), None, None))
+    w = width.value
+    cols = np.empty((ell.num_rows, w), dtype=np.uint32)
+    out = np.empty((ell.num_rows, w), dtype=np.float32)
+    capi.check(l.mispmm_ell_colmajor_to_rowmajor_host(ell.num_rows, ell.num_cols, ell.max_col_nnz, ridx.ctypes.data,
+                                                      vals.ctypes.data, ctypes.byref(width), cols.ctypes.data,
+                                                      out.ctypes.data))
+    return formats.ELLRowMajor(ell.num_rows, ell.num_cols, ell.nnz, w, cols, out)
+
+
+def shard_rows_by_nnz(row_ptrs, parts):
+    rp = np.ascontiguousarray(row_ptrs, dtype=np.uint32)
+    bounds = np.zeros(parts + 1, dtype=np.uint32)
+    capi.check(capi.lib().mispmm_shard_rows_by_nnz_host(rp.shape[0] - 1, rp.ctypes.data, parts, bounds.ctypes.data))
+    return bounds

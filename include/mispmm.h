@@ -1,0 +1,201 @@
+/*
+ * mispmm.h -- C ABI of libmispmm.so, the MI355X (gfx950) SpMM engine.
+ *
+ * This is the drop-in boundary for the reference's SpMM hot path
+ * (mli43/Cuda-Optimization-for-SpMM @ 2024-12-18).  The reference has no FFI:
+ * its engine calls C++ templates `spmm<F>Wrapper<N>(a, b, ref)` that launch CUDA
+ * kernels on raw device pointers held by its format classes.  Each entry point
+ * below is what such a wrapper body binds to (INTEGRATION.md shows the binding);
+ * the reference interface it replaces is cited per function as file:line under
+ * /root/reference.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, ints.  No HIP, torch or C++ types.
+ *   - every `const T *` / `T *` operand of a compute call is a DEVICE pointer
+ *     (hipMalloc'd or any memory the GPU can address) unless the name ends in
+ *     `_host`.  Index type is uint32_t (the reference's MT), values float
+ *     (its DT) -- the only instantiation the reference's kernels have
+ *     (e.g. src/spmm/csr/spmm_csr_k1.cu:86).
+ *   - dense operands are ROW-major with a leading dimension in elements
+ *     (ldb >= N, ldc >= N).  Column-major B (the layout the reference's K2/K4
+ *     ask DenseMatrix::toOrdering for, src/formats/dense.cu:139-191) is
+ *     converted on the device with mispmm_dense_transpose_f32.
+ *   - `stream` is a hipStream_t passed as void*; NULL is the null stream.
+ *     Compute calls only ENQUEUE work: no allocation, no synchronisation, so
+ *     they can be captured into a hipGraph (mispmm_graph_*).
+ *   - return value: MISPMM_OK (0) or a negative mispmm_status; the library
+ *     never calls exit().  mispmm_last_error() gives the detail string of the
+ *     calling thread's last failure.  (The reference prints and exit()s:
+ *     include/cuda_utils.hpp:13-22 -- the host layer above this ABI keeps that
+ *     CLI behaviour.)
+ *   - C is overwritten (beta = 0); it does not need to be zeroed first.
+ */
+#ifndef MISPMM_H
+#define MISPMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISPMM_VERSION 100 /* 0.1.0 */
+
+typedef void *mispmm_stream_t; /* hipStream_t */
+typedef void *mispmm_event_t;  /* hipEvent_t */
+typedef void *mispmm_graph_t;  /* hipGraphExec_t */
+
+enum mispmm_status {
+    MISPMM_OK = 0,
+    MISPMM_ERR_INVALID_ARG = -1, /* null pointer, bad leading dimension, ... */
+    MISPMM_ERR_UNSUPPORTED = -2, /* this kernel id declines the shape (cf. spmm_csr_k4.cu:97-101) */
+    MISPMM_ERR_HIP = -3,         /* a HIP runtime call failed */
+    MISPMM_ERR_NO_DEVICE = -4,
+    MISPMM_ERR_ALLOC = -5
+};
+
+/* How products are accumulated.
+ *  REFERENCE: the rounding sequence of the reference's sequential CPU engine, so
+ *    results are bit-identical to it:
+ *      CSR  fp32 product, widened and summed in a double accumulator in storage
+ *           order, rounded to fp32 once (src/spmm/csr/spmm_csr.cpp:20-25,
+ *           AccT = double from src/main.cu:196);
+ *      COO / ELL / BSR  fp32 product then fp32 add into C, in storage order
+ *           (spmm_coo.cpp:16-24, spmm_ell.cpp:16-29, spmm_bsr.cpp:17-38).
+ *  FAST: fp32 fused multiply-add chain in storage order (<= 1e-5 relative to
+ *    sum|a||b| of the reference result; the MFMA kernels always use this). */
+enum mispmm_acc_mode { MISPMM_ACC_REFERENCE = 0, MISPMM_ACC_FAST = 1 };
+
+/* Kernel selector common to all formats: 0 lets the library choose. */
+#define MISPMM_KERNEL_AUTO 0
+
+/* ------------------------------------------------------------------ runtime */
+int mispmm_version(void);
+const char *mispmm_status_string(int status);
+const char *mispmm_last_error(void);
+
+/* replaces cudaSetDevice(7) (src/main.cu:176) */
+int mispmm_device_count(int *count);
+int mispmm_set_device(int ordinal);
+int mispmm_get_device(int *ordinal);
+/* name buffer >= 256 bytes; cu_count / hbm_bytes may be NULL */
+int mispmm_device_info(int ordinal, char *name, int *cu_count, size_t *hbm_bytes);
+
+/* replace cudaMalloc+cudaMemset / cudaMallocHost / cudaFree / cudaFreeHost as
+ * the format classes use them (src/formats/dense.cu:234-262): device and pinned
+ * host allocations come back zero-filled. */
+int mispmm_malloc(void **dev_ptr, size_t bytes);
+int mispmm_free(void *dev_ptr);
+int mispmm_host_alloc(void **host_ptr, size_t bytes);
+int mispmm_host_free(void *host_ptr);
+
+enum mispmm_copy_kind { MISPMM_H2H = 0, MISPMM_H2D = 1, MISPMM_D2H = 2, MISPMM_D2D = 3 };
+/* blocking copy, as cudaMemcpy in copy2Device/copy2Host (dense.cu:92-137) */
+int mispmm_memcpy(void *dst, const void *src, size_t bytes, int kind);
+int mispmm_memcpy_async(void *dst, const void *src, size_t bytes, int kind, mispmm_stream_t stream);
+int mispmm_memset_async(void *dev_ptr, int value, size_t bytes, mispmm_stream_t stream);
+
+int mispmm_stream_create(mispmm_stream_t *stream);
+int mispmm_stream_destroy(mispmm_stream_t stream);
+int mispmm_stream_sync(mispmm_stream_t stream);
+int mispmm_device_sync(void); /* cudaDeviceSynchronize after each launch, e.g. spmm_csr_k3.cu:83 */
+
+int mispmm_event_create(mispmm_event_t *event);
+int mispmm_event_destroy(mispmm_event_t event);
+int mispmm_event_record(mispmm_event_t event, mispmm_stream_t stream);
+int mispmm_event_sync(mispmm_event_t event);
+int mispmm_event_elapsed_ms(mispmm_event_t start, mispmm_event_t stop, float *ms);
+
+/* Capture everything enqueued on `stream` between begin and end into an
+ * executable graph; replay it with mispmm_graph_launch (launch-bound loops). */
+int mispmm_graph_begin(mispmm_stream_t stream);
+int mispmm_graph_end(mispmm_stream_t stream, mispmm_graph_t *graph);
+int mispmm_graph_launch(mispmm_graph_t graph, mispmm_stream_t stream);
+int mispmm_graph_destroy(mispmm_graph_t graph);
+
+/* -------------------------------------------------------------- CSR x dense */
+/* C[M x N] = A_csr[M x K] * B[K x N].
+ * Replaces the bodies of spmmCSRWrapper1..4 (src/spmm/csr/spmm_csr_k1.cu:36-84,
+ * _k2.cu:60-107, _k3.cu:58-105, _k4.cu:81-142) and their kernels.
+ * kernel: 0 auto; 1 wave-per-row, lane-shuffle broadcast of (col,val);
+ *         2 row-block workgroup, (col,val) staged through LDS;
+ *         3 wave-per-row, (col,val) on the scalar path, B rows by SGPR base;
+ *         4 as 3 with two rows in flight per wave.
+ * Any kernel id handles any M, K, nnz, N, ragged and empty rows. */
+int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                   const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
+                   uint32_t ldc, int kernel, int acc_mode);
+#define MISPMM_CSR_NUM_KERNELS 4
+
+/* -------------------------------------------------------------- ELL x dense */
+/* Row-major ELL: colIdxs/vals are [M x width], padding index 0xFFFFFFFF.
+ * Replaces spmmELLWrapper1/2 (src/spmm/ell/spmm_ell_k1.cu:38-63,
+ * spmm_ell_k2.cu:57-83), which scatter a column-major ELL with atomics; the host
+ * layer converts the reference's column-major arrays once with
+ * mispmm_ell_colmajor_to_rowmajor_host.  kernel: 0 auto, 1 row-group gather. */
+int mispmm_ell_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t width, const uint32_t *colIdxs,
+                   const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int kernel,
+                   int acc_mode);
+#define MISPMM_ELL_NUM_KERNELS 1
+
+/* HOST helper.  rowIdxs_host/vals_host: the reference's SparseMatrixELL arrays,
+ * [numCols x maxColNnz] (src/formats/sparse_ell.cu:36-47).  Call once with
+ * colIdxs_out_host == NULL to get *width_out (longest row), then with buffers of
+ * numRows * width.  Entries of a row keep ascending column, then slot order --
+ * the order spmmELLCpu accumulates them in (spmm_ell.cpp:16-29). */
+int mispmm_ell_colmajor_to_rowmajor_host(uint32_t numRows, uint32_t numCols, uint32_t maxColNnz,
+                                         const uint32_t *rowIdxs_host, const float *vals_host, uint32_t *width_out,
+                                         uint32_t *colIdxs_out_host, float *vals_out_host);
+
+/* -------------------------------------------------------------- BSR x dense */
+/* blocks: numBlocks x (bR x bC) row-major, block-CSR order, any block-column
+ * order inside a block row.  M = numBlockRows * bR.
+ * Replaces spmmBSRWrapper1 (src/spmm/bsr/spmm_bsr_k1.cu:44-91).
+ * kernel: 0 auto; 1 VALU, any bR/bC (REFERENCE or FAST accumulate);
+ *         2 fp32-input MFMA v_mfma_f32_16x16x4_f32, bR = bC = 16 (FAST numerics). */
+int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t bR, uint32_t bC,
+                   uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,
+                   const float *blocks, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int kernel,
+                   int acc_mode);
+#define MISPMM_BSR_NUM_KERNELS 2
+
+/* bf16 blocks and B (raw bf16 bit patterns), fp32 accumulate on
+ * v_mfma_f32_16x16x32_bf16; bR = bC = 16 or 32.  C is fp32 (c_bf16 = 0) or bf16.
+ * New capability (BASELINE.json config 4); the reference has no bf16 path. */
+int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t bR, uint32_t bC,
+                    uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,
+                    const uint16_t *blocks, const uint16_t *B, uint32_t N, uint32_t ldb, void *C, uint32_t ldc,
+                    int c_bf16);
+
+/* -------------------------------------------------------------- COO x dense */
+/* Row-major-sorted COO (the order convert_mtx.py:172-190 writes; rowIdxs must be
+ * non-decreasing).  Replaces spmmCOOWrapper1 (src/spmm/coo/spmm_coo_k1.cu:50-103)
+ * without atomics.  rowPtrs_workspace: device scratch of (M + 1) uint32 the call
+ * fills with row boundaries first; NULL makes every row group binary-search its
+ * range instead (slower, no scratch).  kernel: 0 auto, 1 row-group gather. */
+int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowIdxs,
+                   const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
+                   uint32_t ldc, uint32_t *rowPtrs_workspace, int kernel, int acc_mode);
+#define MISPMM_COO_NUM_KERNELS 1
+
+/* ------------------------------------------------------------ dense helpers */
+/* dst[cols x rows] = transpose(src[rows x cols]); both dense row-major buffers.
+ * Replaces the host round trip of DenseMatrix::toOrdering (dense.cu:139-191). */
+int mispmm_dense_transpose_f32(mispmm_stream_t stream, uint32_t rows, uint32_t cols, const float *src, float *dst);
+/* round-to-nearest-even fp32 -> bf16 bit patterns */
+int mispmm_f32_to_bf16(mispmm_stream_t stream, size_t n, const float *src, uint16_t *dst);
+int mispmm_bf16_to_f32(mispmm_stream_t stream, size_t n, const uint16_t *src, float *dst);
+
+/* ------------------------------------------------------- multi-GPU sharding */
+/* HOST helper: split rows 0..M into `parts` contiguous ranges of near-equal nnz
+ * (prefix search over rowPtrs_host); bounds_out_host has parts + 1 entries,
+ * bounds[0] = 0, bounds[parts] = M.  New capability (the reference is
+ * single-GPU, src/main.cu:176). */
+int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t parts,
+                                  uint32_t *bounds_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISPMM_H */

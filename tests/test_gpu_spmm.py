@@ -1,0 +1,342 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Bars (BASELINE.json north_star, mispmm.h accumulate modes):
+  acc="reference": BIT-EXACT vs the oracle (= the reference CPU engine's rounding
+                   sequence) for CSR, COO, ELL and BSR.
+  acc="fast"     : |c - oracle| <= 1e-5 * sum_k |a_k||b_k| per element (fp32 fma chain;
+                   relative to the magnitude actually summed, so cancellation to ~0
+                   does not make the bound meaningless).
+  bf16 BSR       : inputs rounded to bf16 (RNE) before BOTH oracle and kernel, fp32
+                   accumulate; |c - oracle| <= 2e-6 * sum|a||b| (accumulation order only).
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from mispmm import capi, datasets, formats, ops, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FAST_RTOL = 1e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "pytest -m gpu needs a GPU"
+    assert os.path.exists(capi.LIB_PATH), "libmispmm.so must be built (no fallback path exists)"
+    capi.lib()
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def abs_scale(csr, b):
+    a = formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs, np.abs(csr.data))
+    from oracle import oracle as orc
+    return orc.spmm_csr(a.row_ptrs, a.col_idxs, a.data, np.abs(b)).astype(np.float64)
+
+
+def assert_fast_close(c, ref, scale, rtol=FAST_RTOL):
+    err = np.abs(c.astype(np.float64) - ref.astype(np.float64))
+    bound = rtol * scale + 1e-37
+    assert np.all(err <= bound), f"max err/bound {np.max(err / bound):.3g}"
+
+
+def random_csr(m, k, row_lens, seed):
+    rng = np.random.default_rng(seed)
+    row_lens = np.asarray(row_lens, dtype=np.int64)
+    ptr = np.concatenate([[0], np.cumsum(row_lens)]).astype(np.uint32)
+    cols = np.concatenate([np.sort(rng.choice(k, size=n, replace=False)) for n in row_lens] + [np.zeros(0, np.int64)])
+    vals = rng.uniform(-2, 2, size=int(ptr[-1])).astype(np.float32)
+    return formats.CSR(m, k, ptr, cols.astype(np.uint32), vals)
+
+
+# --------------------------------------------------------------------------- CSR
+CSR_CASES = [("Hamrle1", [1, 3, 32]), ("n3c5-b6", [8, 21]), ("qh1484", [64, 130]), ("delaunay_n12", [128]),
+             ("GL7d25", [64, 100]), ("ACTIVSg10K", [128]), ("n4c6-b13", [128, 256, 512, 515])]
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,ns", CSR_CASES)
+def test_csr_matches_oracle(oracle, name, ns, kernel):
+    csr = datasets.load_csr(name)
+    a = ops.DeviceCSR.from_host(csr)
+    for n in ns:
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        bd = dev(b)
+        c = ops.spmm_csr(a, bd, kernel=kernel, acc="reference").cpu().numpy()
+        assert np.array_equal(c, ref), f"{name} N={n} k{kernel}: reference mode must be bit-exact"
+        cf = ops.spmm_csr(a, bd, kernel=kernel, acc="fast").cpu().numpy()
+        assert_fast_close(cf, ref, abs_scale(csr, b))
+
+
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+def test_csr_ragged_rows_and_edges(oracle, kernel):
+    """Empty rows, rows of 1, 17, 64, 65, 200 and 2500 entries (k2 re-stages LDS past 1024
+    pairs, k3/k4 loop 64-pair chunks), M not a multiple of any tile."""
+    lens = [0, 1, 17, 64, 65, 200, 0, 2500, 3, 0, 16, 15, 33, 8, 4, 5, 9, 0, 0, 1300, 7]
+    csr = random_csr(len(lens), 3000, lens, seed=7)
+    a = ops.DeviceCSR.from_host(csr)
+    for n in (1, 2, 5, 64, 72, 128, 260):
+        b = synth.dense_b(csr.num_cols, n, seed=n)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        c = ops.spmm_csr(a, dev(b), kernel=kernel, acc="reference").cpu().numpy()
+        assert np.array_equal(c, ref), f"N={n}"
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+def test_csr_strided_and_unaligned_operands(oracle, kernel):
+    csr = datasets.load_csr("qh1484")
+    a = ops.DeviceCSR.from_host(csr)
+    n = 96
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for ldb, ldc, shift in ((n, n, 0), (n + 32, n + 64, 0), (n + 1, n + 3, 0), (n + 4, n + 4, 1), (n + 2, n + 2, 2)):
+        big_b = torch.zeros(csr.num_cols * ldb + 8, dtype=torch.float32, device="cuda")
+        bview = big_b[shift:shift + csr.num_cols * ldb].view(csr.num_cols, ldb)[:, :n]
+        bview.copy_(dev(b))
+        big_c = torch.full((csr.num_rows * ldc + 8,), -7.0, dtype=torch.float32, device="cuda")
+        cview = big_c[shift:shift + csr.num_rows * ldc].view(csr.num_rows, ldc)[:, :n]
+        ops.spmm_csr(a, bview, out=cview, kernel=kernel)
+        assert np.array_equal(cview.cpu().numpy(), ref), (ldb, ldc, shift)
+        full = big_c[shift:shift + csr.num_rows * ldc].view(csr.num_rows, ldc).cpu().numpy()
+        assert np.all(full[:, n:] == -7.0), "columns past N must not be written"
+
+
+def test_csr_empty_and_overwrite():
+    empty = formats.CSR(5, 9, np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    c = torch.full((5, 16), 3.0, device="cuda")
+    ops.spmm_csr(ops.DeviceCSR.from_host(empty), torch.ones(9, 16, device="cuda"), out=c)
+    assert torch.all(c == 0), "beta = 0: C is overwritten even for an all-zero A"
+    none = formats.CSR(0, 9, np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    assert ops.spmm_csr(ops.DeviceCSR.from_host(none), torch.ones(9, 4, device="cuda")).shape == (0, 4)
+
+
+def test_csr_nonfinite_values_follow_the_reference(oracle):
+    csr = random_csr(4, 40, [3, 14, 16, 20], seed=3)
+    b = synth.dense_b(40, 64)
+    b[csr.col_idxs[5], 3] = np.inf
+    b[csr.col_idxs[20], 7] = np.nan
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    a = ops.DeviceCSR.from_host(csr)
+    for k in (1, 2, 3, 4):
+        c = ops.spmm_csr(a, dev(b), kernel=k).cpu().numpy()
+        assert np.array_equal(c, ref, equal_nan=True)
+
+
+def test_exact_grid_inputs_make_every_kernel_and_format_agree_bitwise(oracle):
+    """Headline matrix (values +-1) times a 2^-8-grid B: all partial sums are exact in fp32, so
+    every kernel, accumulate mode and format must return identical bits -- a full-size,
+    order-independent check."""
+    csr = datasets.load_csr("n4c6-b13")
+    b = synth.dense_b(csr.num_cols, 128, mode="exact")
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    bd = dev(b)
+    a = ops.DeviceCSR.from_host(csr)
+    for k in (1, 2, 3, 4):
+        for acc in ("reference", "fast"):
+            assert np.array_equal(ops.spmm_csr(a, bd, kernel=k, acc=acc).cpu().numpy(), ref)
+    ell = ops.DeviceELL.from_host(formats.csr_to_ell_colmajor(csr))
+    coo = ops.DeviceCOO.from_host(formats.csr_to_coo(csr))
+    for acc in ("reference", "fast"):
+        assert np.array_equal(ops.spmm_ell(ell, bd, acc=acc).cpu().numpy(), ref)
+        assert np.array_equal(ops.spmm_coo(coo, bd, acc=acc).cpu().numpy(), ref)
+
+
+def test_golden_fixtures_through_the_gpu(golden_dir):
+    """The reference's committed result.expect files and the reduced expectations of the large
+    configs (tests/golden/make_golden.py), straight through the HIP path."""
+    from test_oracle import LARGE, check_large
+    for d, stem in (("small_10x10", "sparse"), ("small_32x32", "Hamrle1")):
+        csr = formats.read_csr(os.path.join(golden_dir, d, stem + ".csr"))
+        b = formats.read_dense(os.path.join(golden_dir, d, "dense.in")).data
+        expect = np.loadtxt(os.path.join(golden_dir, d, "result.expect"), ndmin=2)
+        c = ops.spmm_csr(ops.DeviceCSR.from_host(csr), dev(b)).cpu().numpy()
+        scale = np.abs(csr.to_dense()).astype(np.float64) @ np.abs(b).astype(np.float64)
+        assert np.all(np.abs(c - expect) <= 2e-6 * scale + 1e-9)
+    z = np.load(os.path.join(golden_dir, "expected_large.npz"))
+    for tag, name, k, mode in LARGE:
+        csr = datasets.load_csr(name)
+        b = dev(synth.dense_b(csr.num_cols, k, mode=mode))
+        for acc in ("reference", "fast"):
+            check_large(ops.spmm_csr(ops.DeviceCSR.from_host(csr), b, acc=acc).cpu().numpy(), z, tag)
+
+
+def test_graph_replay_equals_eager(oracle):
+    import ctypes
+    csr = datasets.load_csr("n4c6-b13")
+    a = ops.DeviceCSR.from_host(csr)
+    b = dev(synth.dense_b(csr.num_cols, 128))
+    eager = ops.spmm_csr(a, b, kernel=3).cpu().numpy()
+    l = capi.lib()
+    s = torch.cuda.Stream()
+    c = torch.zeros((csr.num_rows, 128), device="cuda")
+    torch.cuda.synchronize()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    capi.check(l.mispmm_graph_begin(sp))
+    for _ in range(5):
+        ops.spmm_csr(a, b, out=c, kernel=3, stream=s)
+    g = ctypes.c_void_p()
+    capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
+    assert torch.all(c == 0), "capture must not execute"
+    capi.check(l.mispmm_graph_launch(g, sp))
+    capi.check(l.mispmm_stream_sync(sp))
+    assert np.array_equal(c.cpu().numpy(), eager)
+    capi.check(l.mispmm_graph_destroy(g))
+
+
+# --------------------------------------------------------------------------- ELL / COO
+@pytest.mark.parametrize("name,ns", [("Hamrle1", [3, 32]), ("n3c5-b6", [21]), ("delaunay_n12", [128, 130]),
+                                     ("n4c6-b13", [256]), ("ACTIVSg10K", [64])])
+def test_ell_matches_oracle(oracle, name, ns):
+    csr = datasets.load_csr(name)
+    for ref_width in (True, False):
+        if ref_width and np.diff(csr.row_ptrs.astype(np.int64)).max() < np.bincount(csr.col_idxs).max():
+            continue   # the reference-sized padding cannot hold this matrix's longest column
+        ellc = formats.csr_to_ell_colmajor(csr, reference_width=ref_width)
+        a = ops.DeviceELL.from_host(ellc)
+        for n in ns:
+            b = synth.dense_b(csr.num_cols, n)
+            ref = oracle.spmm_ell_colmajor(ellc.num_rows, ellc.row_idxs, ellc.data, b)
+            c = ops.spmm_ell(a, dev(b), acc="reference").cpu().numpy()
+            assert np.array_equal(c, ref), f"{name} N={n}"
+            assert_fast_close(ops.spmm_ell(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+
+
+def test_ell_padding_anywhere_and_wide_rows(oracle):
+    rng = np.random.default_rng(5)
+    m, k, w = 37, 500, 150
+    cols = np.full((m, w), formats.ELL_PAD, dtype=np.uint32)
+    vals = np.zeros((m, w), dtype=np.float32)
+    for r in range(m):
+        n = int(rng.integers(0, w + 1))
+        slots = np.sort(rng.choice(w, size=n, replace=False))          # padding holes in the middle
+        cols[r, slots] = np.sort(rng.choice(k, size=n, replace=False))
+        vals[r, slots] = rng.uniform(-1, 1, n)
+    ell = formats.ELLRowMajor(m, k, int((cols != formats.ELL_PAD).sum()), w, cols, vals)
+    b = synth.dense_b(k, 40)
+    ref = np.zeros((m, 40), np.float32)
+    for r in range(m):                      # fp32 += in slot order, unfused, as spmmELLCpu sums a row
+        for s in range(w):
+            if cols[r, s] != formats.ELL_PAD:
+                ref[r] = ref[r] + vals[r, s] * b[cols[r, s]]
+    c = ops.spmm_ell(ops.DeviceELL.from_host(ell), dev(b)).cpu().numpy()
+    assert np.array_equal(c, ref)
+
+
+@pytest.mark.parametrize("workspace", [True, False])
+@pytest.mark.parametrize("name,ns", [("Hamrle1", [5, 32]), ("qh1484", [64]), ("n4c6-b13", [128]), ("GL7d25", [30])])
+def test_coo_matches_oracle(oracle, name, ns, workspace):
+    csr = datasets.load_csr(name)
+    coo = formats.csr_to_coo(csr)
+    a = ops.DeviceCOO.from_host(coo)
+    for n in ns:
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, b)
+        c = ops.spmm_coo(a, dev(b), workspace=workspace).cpu().numpy()
+        assert np.array_equal(c, ref), f"{name} N={n}"
+        assert_fast_close(ops.spmm_coo(a, dev(b), acc="fast", workspace=workspace).cpu().numpy(), ref, abs_scale(csr, b))
+
+
+def test_coo_with_empty_leading_and_trailing_rows(oracle):
+    coo = formats.COO(9, 6, np.array([2, 2, 5, 5, 5, 6], np.uint32), np.array([0, 3, 1, 2, 5, 4], np.uint32),
+                      np.array([1, -2, 3, 4, -5, 6], np.float32))
+    b = synth.dense_b(6, 12)
+    ref = oracle.spmm_coo(9, coo.row_idxs, coo.col_idxs, coo.data, b)
+    for ws in (True, False):
+        assert np.array_equal(ops.spmm_coo(ops.DeviceCOO.from_host(coo), dev(b), workspace=ws).cpu().numpy(), ref)
+
+
+# --------------------------------------------------------------------------- BSR
+@pytest.mark.parametrize("name,block,ns", [("Hamrle1", 1, [32]), ("Hamrle1", 4, [7, 32]), ("n3c5-b6", 2, [21]),
+                                           ("qh1484", 4, [64]), ("ACTIVSg10K", 16, [128]), ("ACTIVSg10K", 32, [64]),
+                                           ("dw1024", 16, [100])])
+def test_bsr_valu_matches_oracle(oracle, name, block, ns):
+    csr = datasets.load_csr(name)
+    bsr = formats.csr_to_bsr(csr, block)
+    a = ops.DeviceBSR.from_host(bsr)
+    for n in ns:
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_bsr(bsr.num_rows, block, block, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, b)
+        c = ops.spmm_bsr(a, dev(b), kernel=1, acc="reference").cpu().numpy()
+        assert np.array_equal(c, ref), f"{name} b{block} N={n}"
+        assert_fast_close(ops.spmm_bsr(a, dev(b), kernel=1, acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+
+
+def test_bsr_rectangular_blocks_and_unsorted_block_columns(oracle):
+    rng = np.random.default_rng(11)
+    br, bc, mb, kb = 3, 5, 7, 9
+    ptrs, idxs = [0], []
+    for _ in range(mb):
+        n = int(rng.integers(0, kb + 1))
+        idxs += list(rng.permutation(kb)[:n])           # storage order is NOT ascending
+        ptrs.append(len(idxs))
+    data = rng.uniform(-1, 1, (len(idxs), br, bc)).astype(np.float32)
+    bsr = formats.BSR(mb * br, kb * bc, data.size, br, bc, np.array(ptrs, np.uint32), np.array(idxs, np.uint32), data)
+    b = synth.dense_b(kb * bc, 24)
+    ref = oracle.spmm_bsr(bsr.num_rows, br, bc, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, b)
+    assert np.array_equal(ops.spmm_bsr(ops.DeviceBSR.from_host(bsr), dev(b), kernel=1).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("name,n", [("ACTIVSg10K", 128), ("ACTIVSg10K", 72), ("dw1024", 64), ("qh1484", 256)])
+def test_bsr_mfma_f32_equals_fast_valu_bitwise(oracle, name, n):
+    """v_mfma_f32_16x16x4_f32 is an exact k-ordered fma chain and the kernel maps k to ascending
+    block columns: same bits as the FAST VALU kernel, and within 1e-5 of the oracle."""
+    csr = datasets.load_csr(name)
+    pad = (-csr.num_rows) % 16, (-csr.num_cols) % 16
+    if any(pad):
+        csr = formats.CSR(csr.num_rows + pad[0], csr.num_cols + pad[1],
+                          np.concatenate([csr.row_ptrs, np.full(pad[0], csr.row_ptrs[-1], np.uint32)]), csr.col_idxs, csr.data)
+    bsr = formats.csr_to_bsr(csr, 16)
+    a = ops.DeviceBSR.from_host(bsr)
+    b = synth.dense_b(csr.num_cols, n)
+    valu = ops.spmm_bsr(a, dev(b), kernel=1, acc="fast").cpu().numpy()
+    mfma = ops.spmm_bsr(a, dev(b), kernel=2, acc="fast").cpu().numpy()
+    assert np.array_equal(mfma, valu)
+    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, b)
+    assert_fast_close(mfma, ref, abs_scale(csr, b))
+    assert np.array_equal(ops.spmm_bsr(a, dev(b), kernel=0, acc="fast").cpu().numpy(), mfma)   # auto picks MFMA
+
+
+@pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (4, False)])
+def test_bsr_bf16_mfma(oracle, n, out_bf16):
+    """BASELINE config 4 (large_20000 BSR-16 x K=128 bf16).  Oracle = the reference's BSR CPU
+    semantics on bf16-rounded A and B (the reference itself has no bf16)."""
+    csr = datasets.load_csr("ACTIVSg10K")
+    bsr = formats.csr_to_bsr(csr, 16)
+    a = ops.DeviceBSR.from_host(bsr)
+    b = synth.dense_b(csr.num_cols, n)
+    a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    blocks_bits = ops.f32_to_bf16(a.data)
+    b_bits = ops.f32_to_bf16(dev(b))
+    assert np.array_equal(ops.bf16_to_f32(blocks_bits).cpu().numpy().reshape(a16.shape), a16), "device RNE == host RNE"
+    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    c = ops.spmm_bsr_bf16(a, blocks_bits, b_bits, out_bf16=out_bf16)
+    got = (ops.bf16_to_f32(c) if out_bf16 else c).cpu().numpy()
+    scale = abs_scale(formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs,
+                                  synth.bf16_round(csr.data)), b16)
+    if out_bf16:
+        assert np.all(np.abs(got - ref) <= 2 ** -8 * np.abs(ref) + 2e-6 * scale + 1e-30)
+    else:
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+
+
+# --------------------------------------------------------------------------- dense helpers
+@pytest.mark.parametrize("shape", [(1, 1), (3, 130), (64, 64), (257, 65), (1000, 31)])
+def test_dense_transpose(shape):
+    x = torch.arange(shape[0] * shape[1], dtype=torch.float32, device="cuda").view(shape)
+    assert torch.equal(ops.dense_transpose(x), x.t().contiguous())
+
+
+def test_bf16_conversion_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.01171875, -3.3, 0.0, -0.0, np.inf, 65504.0, 1e-40], np.float32)
+    bits = ops.f32_to_bf16(dev(x))
+    back = ops.bf16_to_f32(bits).cpu().numpy()
+    assert np.array_equal(back, synth.bf16_round(x))
+    assert np.isnan(ops.bf16_to_f32(ops.f32_to_bf16(dev(np.array([np.nan], np.float32)))).cpu().numpy()[0])
