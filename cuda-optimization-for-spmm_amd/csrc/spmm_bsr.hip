@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void bsr_valu(uint32_t M, uint32_t bR, uint32_
 __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                     const uint32_t *__restrict__ blockColIdxs,
                                                     const float *__restrict__ blocks, const float *__restrict__ B,
-                                                    uint32_t N, uint32_t ldb, float *__restrict__ C, uint32_t ldc) {
+                                                    uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
+                                                    uint32_t ldc) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + wave;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
     const uint32_t ncol = st * 64 + c * 4;  // first of this lane's 4 interleaved output columns
-    const rsrc_t rsrc = make_rsrc(B, N * 4u);  // one B row; columns past N read as zero
-    const uint32_t lane_off = ncol * 4u;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = ncol < N ? ncol * 4u : kDropLoad;  // columns past N read as zero
     const uint32_t ldb4 = ldb * 4u;
 
     f32x4_t acc[4];
@@ -159,7 +160,8 @@ template <bool C_BF16>
 __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
-                                                     uint32_t N, uint32_t ldb, void *__restrict__ Cv, uint32_t ldc) {
+                                                     uint32_t b_bytes, uint32_t N, uint32_t ldb, void *__restrict__ Cv,
+                                                     uint32_t ldc) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = blockIdx.x * 4 + wave;
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
     const uint32_t ncol = st * 64 + c * 4;
-    const rsrc_t rsrc = make_rsrc(B, N * 2u);
-    const uint32_t lane_off = ncol * 2u;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
     const uint32_t ldb2 = ldb * 2u;
     const uint32_t khalf = (g & 1) * 8u;  // first block column of this lane's 8 k slots
 
@@ -265,10 +267,10 @@ static void launch_valu_v(const BsrArgs &a, int vec) {
 
 static bool mfma_shape_ok(uint32_t K, uint32_t N, uint32_t ldb, uint32_t ldc, const void *B, const void *C,
                           const void *blocks, size_t elem) {
-    // whole 16-byte (fp32) / 8-byte (bf16) vectors of 4 columns; scalar offsets must fit 32 bits
+    // whole 16-byte (fp32) / 8-byte (bf16) vectors of 4 columns; B must fit a < 2 GiB buffer descriptor
     return N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(blocks) &&
            (reinterpret_cast<uintptr_t>(B) % (4 * elem) == 0) && (reinterpret_cast<uintptr_t>(C) % 8 == 0) &&
-           static_cast<uint64_t>(K) * ldb * elem <= 0xFFFFFFFFull;
+           static_cast<uint64_t>(K) * ldb * elem <= 0x7FFFFFFFull;
 }
 
 }  // namespace mispmm
@@ -297,7 +299,8 @@ extern "C" int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uin
     if (kernel == 2) {
         const uint32_t nST = ceil_div(N, 64u);
         hipLaunchKernelGGL(bsr_mfma_f32, dim3(ceil_div(numBlockRows * nST, 4u)), dim3(256), 0, st, numBlockRows, nST,
-                           blockRowPtrs, blockColIdxs, blocks, B, N, ldb, C, ldc);
+                           blockRowPtrs, blockColIdxs, blocks, B, static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u),
+                           N, ldb, C, ldc);
     } else {
         const BsrArgs a{st, numBlockRows, K, bR, bC, blockRowPtrs, blockColIdxs, blocks, B, N, ldb, C, ldc};
         const int vec = pick_vec(B, ldb, C, ldc, N);
@@ -321,12 +324,13 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
         return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: N/ldb/ldc must be multiples of 4 and operands vector-aligned");
     const uint32_t nST = ceil_div(N, 64u);
     dim3 grid(ceil_div(numBlockRows * nST, 4u));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
     if (c_bf16)
         hipLaunchKernelGGL(bsr_mfma_bf16<true>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, N, ldb, C, ldc);
+                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc);
     else
         hipLaunchKernelGGL(bsr_mfma_bf16<false>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, N, ldb, C, ldc);
+                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

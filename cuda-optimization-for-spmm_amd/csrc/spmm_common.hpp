@@ -31,9 +31,10 @@ __device__ __forceinline__ void vec_set(typename VecOf<VEC>::type &v, int i, flo
 }
 
 // ---- bounds-checked buffer loads --------------------------------------------------------------
-// B is read through a raw buffer descriptor: `voffset` (per lane) is range-checked against the
-// descriptor's byte count, `soffset` (wave-uniform SGPR) is not.  A load whose voffset has bit 31
-// set is out of range: the hardware returns zeros and fetches nothing, which is how the kernels
+// B is read through a raw buffer descriptor spanning all of B (< 2 GiB): the hardware range-checks
+// voffset (per lane) + soffset (wave-uniform SGPR) against the descriptor's byte count (measured on
+// gfx950: soffset IS part of the check).  A load whose voffset has bit 31 set is therefore out of
+// range whatever the soffset: it returns zeros and fetches nothing, which is how the kernels
 // drop the unused slots of a fixed-size load batch without branching around a load (a branch
 // there makes hipcc drain vmcnt before the next load and serialises the gather).
 using rsrc_t = __amdgpu_buffer_rsrc_t;

@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256) void csr_k2(uint32_t M, const uint32_t *__rest
 // A chunk of up to 64 (col, val) pairs is fetched by ONE coalesced vector load per array (lane i
 // holds pair i; the next chunk is prefetched while this one is consumed).  v_readlane moves each
 // column to an SGPR, scaled to the byte offset of that B row, which rides in the buffer load's
-// scalar offset: `buffer_load_dwordxN v, v_lane_off, s[rsrc], s_row_off offen`.  The descriptor
-// spans one row's N*4 bytes, so lanes past N (and the unused slots of the last batch, via
-// kDropLoad) fetch nothing.  B reads go out 16 per lane per row; ROWS rows are interleaved per
+// scalar offset: `buffer_load_dwordxN v, v_lane_off, s[rsrc], s_row_off offen`.  (gfx950 range-checks
+// voffset + soffset against the descriptor, so the descriptor spans all of B.)  Lanes past N and
+// the unused slots of the last batch carry kDropLoad and fetch nothing.  B reads go out 16 per lane per row; ROWS rows are interleaved per
 // wave (k4 = 2) to halve the wave count and double the loads in flight.
 // One batch: U B-row reads per row issued back to back, then U multiply-adds per row in storage
 // order.  Slots at or past the row's count are dropped loads (zeros) times a zeroed coefficient:
@@ -253,7 +253,7 @@ __device__ __forceinline__ void wave_batch(rsrc_t rsrc, uint32_t lane_off, uint3
 template <int VEC, int ROWS, class Acc>
 __global__ __launch_bounds__(256) void csr_k3(uint32_t M, const uint32_t *__restrict__ rowPtrs,
                                               const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
-                                              const float *__restrict__ B, uint32_t N, uint32_t ldb,
+                                              const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
                                               float *__restrict__ C, uint32_t ldc) {
     using vec_t = typename VecOf<VEC>::type;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(256) void csr_k3(uint32_t M, const uint32_t *__rest
     if (row0 >= M) return;  // wave-uniform exit
     const uint32_t col0 = blockIdx.y * (64 * VEC) + lane * VEC;
     const bool col_ok = col0 < N;
-    const rsrc_t rsrc = make_rsrc(B, N * 4u);
-    const uint32_t lane_off = col0 * 4u;  // >= N*4 for lanes past N: dropped by the range check
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;  // lanes past N never fetch
     const uint32_t ldb4 = ldb * 4u;
 
     uint32_t pos[ROWS], end[ROWS];
@@ -380,8 +380,9 @@ static void launch_grouped_g(const CsrArgs &a, int kernel, int g, bool wide) {
 template <int VEC, int ROWS, class Acc>
 static void launch_wave(const CsrArgs &a) {
     dim3 grid(ceil_div(a.M, 4 * ROWS), ceil_div(a.N, 64 * VEC));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     hipLaunchKernelGGL((csr_k3<VEC, ROWS, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
-                       a.N, a.ldb, a.C, a.ldc);
+                       b_bytes, a.N, a.ldb, a.C, a.ldc);
 }
 
 template <class Acc>
