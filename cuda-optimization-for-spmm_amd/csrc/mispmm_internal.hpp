@@ -35,4 +35,11 @@ inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// XCD-aware workgroup order (device half: xcd_block() in spmm_common.hpp): blocks to launch and the
+// chunk to pass for `nblk` logical row blocks; chunk 0 = keep dispatch order.
+struct XcdGrid {
+    uint32_t grid, chunk;
+};
+XcdGrid xcd_grid(uint32_t nblk);
+
 }  // namespace mispmm

@@ -1,5 +1,6 @@
 // Runtime slice of the C ABI: device selection, memory, streams, events, graphs.
 // Lets the C++ host layer (host/) stay free of HIP headers.
+#include <cstdlib>
 #include <cstring>
 
 #include "mispmm_internal.hpp"
@@ -21,6 +22,17 @@ int fail(int status, const char *fmt, ...) {
     vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
     return status;
+}
+
+XcdGrid xcd_grid(uint32_t nblk) {
+    // MISPMM_XCD_REMAP=0 disables the renumbering (A/B measurements only)
+    static const bool enabled = [] {
+        const char *e = getenv("MISPMM_XCD_REMAP");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled || nblk < 16) return {nblk, 0u};
+    const uint32_t chunk = (nblk + 7u) / 8u;
+    return {chunk * 8u, chunk};
 }
 
 }  // namespace mispmm

@@ -121,12 +121,13 @@ int mispmm_graph_destroy(mispmm_graph_t graph);
  * kernel: 0 auto; 1 wave-per-row, lane-shuffle broadcast of (col,val);
  *         2 row-block workgroup, (col,val) staged through LDS;
  *         3 wave-per-row, (col,val) on the scalar path, B rows by SGPR base;
- *         4 as 3 with two rows in flight per wave.
+ *         4 as 3 with two rows in flight per wave;
+ *         5 as 1 with a 2-D (row part x column part) XCD tiling and write-through C stores.
  * Any kernel id handles any M, K, nnz, N, ragged and empty rows. */
 int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
                    const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
                    uint32_t ldc, int kernel, int acc_mode);
-#define MISPMM_CSR_NUM_KERNELS 4
+#define MISPMM_CSR_NUM_KERNELS 5
 
 /* -------------------------------------------------------------- ELL x dense */
 /* Row-major ELL: colIdxs/vals are [M x width], padding index 0xFFFFFFFF.

@@ -60,7 +60,7 @@ CSR_CASES = [("Hamrle1", [1, 3, 32]), ("n3c5-b6", [8, 21]), ("qh1484", [64, 130]
              ("GL7d25", [64, 100]), ("ACTIVSg10K", [128]), ("n4c6-b13", [128, 256, 512, 515])]
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("name,ns", CSR_CASES)
 def test_csr_matches_oracle(oracle, name, ns, kernel):
     csr = datasets.load_csr(name)
@@ -75,7 +75,7 @@ def test_csr_matches_oracle(oracle, name, ns, kernel):
         assert_fast_close(cf, ref, abs_scale(csr, b))
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
 def test_csr_ragged_rows_and_edges(oracle, kernel):
     """Empty rows, rows of 1, 17, 64, 65, 200 and 2500 entries (k2 re-stages LDS past 1024
     pairs, k3/k4 loop 64-pair chunks), M not a multiple of any tile."""
@@ -89,7 +89,7 @@ def test_csr_ragged_rows_and_edges(oracle, kernel):
         assert np.array_equal(c, ref), f"N={n}"
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
 def test_csr_strided_and_unaligned_operands(oracle, kernel):
     csr = datasets.load_csr("qh1484")
     a = ops.DeviceCSR.from_host(csr)
@@ -124,7 +124,7 @@ def test_csr_nonfinite_values_follow_the_reference(oracle):
     b[csr.col_idxs[20], 7] = np.nan
     ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
     a = ops.DeviceCSR.from_host(csr)
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5):
         c = ops.spmm_csr(a, dev(b), kernel=k).cpu().numpy()
         assert np.array_equal(c, ref, equal_nan=True)
 
@@ -138,7 +138,7 @@ def test_exact_grid_inputs_make_every_kernel_and_format_agree_bitwise(oracle):
     ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
     bd = dev(b)
     a = ops.DeviceCSR.from_host(csr)
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5):
         for acc in ("reference", "fast"):
             assert np.array_equal(ops.spmm_csr(a, bd, kernel=k, acc=acc).cpu().numpy(), ref)
     ell = ops.DeviceELL.from_host(formats.csr_to_ell_colmajor(csr))

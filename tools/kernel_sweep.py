@@ -18,6 +18,51 @@ sys.path.insert(0, os.path.join(ROOT, "cuda-optimization-for-spmm_amd"))
 from mispmm import capi, datasets, ops, synth  # noqa: E402
 
 
+def greedy_cluster(csr, parts):
+    """Greedy growth of `parts` balanced row clusters maximising shared columns (experiment aid)."""
+    import heapq
+    import scipy.sparse as sp
+    m, k = csr.num_rows, csr.num_cols
+    indptr, ind = csr.row_ptrs.astype(np.int64), csr.col_idxs.astype(np.int64)
+    at = sp.csr_matrix((np.ones(csr.nnz), ind, indptr), shape=(m, k)).T.tocsr()
+    cap = -(-m // parts)
+    unassigned = np.ones(m, bool)
+    order, nxt = [], 0
+    for _ in range(parts):
+        colin, gain, heap, size = np.zeros(k, bool), np.zeros(m, np.int64), [], 0
+        while nxt < m and not unassigned[nxt]:
+            nxt += 1
+        r = nxt if nxt < m else None
+        while size < cap and r is not None:
+            order.append(r); unassigned[r] = False; size += 1
+            for c in ind[indptr[r]:indptr[r + 1]]:
+                if not colin[c]:
+                    colin[c] = True
+                    for r2 in at.indices[at.indptr[c]:at.indptr[c + 1]]:
+                        if unassigned[r2]:
+                            gain[r2] += 1
+                            heapq.heappush(heap, (-gain[r2], r2))
+            r = None
+            while heap:
+                g, r2 = heapq.heappop(heap)
+                if unassigned[r2] and -g == gain[r2]:
+                    r = r2
+                    break
+            if r is None:
+                while nxt < m and not unassigned[nxt]:
+                    nxt += 1
+                r = nxt if nxt < m else None
+    return np.array(order)
+
+
+def permute_rows(csr, order):
+    from mispmm import formats
+    lens = np.diff(csr.row_ptrs.astype(np.int64))[order]
+    ptr = np.concatenate([[0], np.cumsum(lens)])
+    idx = np.concatenate([np.arange(csr.row_ptrs[r], csr.row_ptrs[r + 1]) for r in order]).astype(np.int64)
+    return formats.CSR(csr.num_rows, csr.num_cols, ptr.astype(np.uint32), csr.col_idxs[idx], csr.data[idx])
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--matrix", default="n4c6-b13")
@@ -25,9 +70,12 @@ def main():
     p.add_argument("--iters", type=int, default=500)
     p.add_argument("--rounds", type=int, default=5)
     p.add_argument("--kernels", default="1,2,3,4")
+    p.add_argument("--cluster", type=int, default=0, help="permute rows by greedy clustering into this many parts")
     args = p.parse_args()
     l = capi.lib()
     csr = datasets.load_csr(args.matrix)
+    if args.cluster:
+        csr = permute_rows(csr, greedy_cluster(csr, args.cluster))
     a = ops.DeviceCSR.from_host(csr)
     b = torch.from_numpy(synth.dense_b(csr.num_cols, args.k_cols)).cuda()
     c = torch.empty((csr.num_rows, args.k_cols), device="cuda")
