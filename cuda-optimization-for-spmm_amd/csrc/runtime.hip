@@ -2,6 +2,8 @@
 // Lets the C++ host layer (host/) stay free of HIP headers.
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 
 #include "mispmm_internal.hpp"
 
@@ -107,19 +109,44 @@ int mispmm_free(void *dev_ptr) {
     return MISPMM_OK;
 }
 
+// Pinned host memory needs a device context.  On a machine without a GPU (the CLI's --cpu-only
+// path, BASELINE config 1) the allocation degrades to ordinary page-aligned memory; those
+// pointers are remembered so mispmm_host_free releases them the right way.
+static std::mutex g_plain_mutex;
+static std::unordered_set<void *> g_plain_host;
+
 int mispmm_host_alloc(void **host_ptr, size_t bytes) {
     if (!host_ptr) return fail(MISPMM_ERR_INVALID_ARG, "host_ptr is null");
     *host_ptr = nullptr;
     if (bytes == 0) return MISPMM_OK;
     hipError_t e = hipHostMalloc(host_ptr, bytes, hipHostMallocDefault);
-    if (e == hipErrorOutOfMemory) return fail(MISPMM_ERR_ALLOC, "hipHostMalloc(%zu) out of memory", bytes);
-    MISPMM_HIP_TRY(e);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) {
+        (void)hipGetLastError();
+        void *p = nullptr;
+        if (posix_memalign(&p, 4096, bytes) != 0) return fail(MISPMM_ERR_ALLOC, "posix_memalign(%zu) failed", bytes);
+        std::lock_guard<std::mutex> lock(g_plain_mutex);
+        g_plain_host.insert(p);
+        *host_ptr = p;
+    } else {
+        if (e == hipErrorOutOfMemory) return fail(MISPMM_ERR_ALLOC, "hipHostMalloc(%zu) out of memory", bytes);
+        MISPMM_HIP_TRY(e);
+    }
     memset(*host_ptr, 0, bytes);
     return MISPMM_OK;
 }
 
 int mispmm_host_free(void *host_ptr) {
-    if (host_ptr) MISPMM_HIP_TRY(hipHostFree(host_ptr));
+    if (!host_ptr) return MISPMM_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_plain_mutex);
+        auto it = g_plain_host.find(host_ptr);
+        if (it != g_plain_host.end()) {
+            g_plain_host.erase(it);
+            free(host_ptr);
+            return MISPMM_OK;
+        }
+    }
+    MISPMM_HIP_TRY(hipHostFree(host_ptr));
     return MISPMM_OK;
 }
 

@@ -1,0 +1,69 @@
+#include "formats/sparse_coo.hpp"
+
+namespace cuspmm {
+
+template <typename DT, typename MT> SparseMatrixCOO<DT, MT>::SparseMatrixCOO(std::string filePath) {
+    std::ifstream in(filePath);
+    if (!in.is_open()) {
+        std::cerr << "File " << filePath << " doesn't exist!" << std::endl;
+        throw std::runtime_error("cannot open " + filePath);
+    }
+    in >> this->numRows >> this->numCols >> this->numNonZero;
+    this->allocateSpace(false);
+    for (size_t i = 0; i < this->numNonZero; ++i) in >> this->rowIdxs[i] >> this->colIdxs[i] >> this->data[i];
+    if (in.fail()) throw std::runtime_error(filePath + ": truncated or malformed .coo file");
+}
+
+template <typename DT, typename MT>
+SparseMatrixCOO<DT, MT>::SparseMatrixCOO(MT numRows, MT numCols, MT numNonZero, bool onDevice) {
+    this->numRows = numRows;
+    this->numCols = numCols;
+    this->numNonZero = numNonZero;
+    this->allocateSpace(onDevice);
+}
+
+template <typename DT, typename MT> SparseMatrixCOO<DT, MT>::~SparseMatrixCOO() {
+    releaseBuffer(this->rowIdxs, this->onDevice);
+    releaseBuffer(this->colIdxs, this->onDevice);
+    releaseBuffer(this->data, this->onDevice);
+    releaseBuffer(this->rowBoundsWorkspace, true);
+}
+
+template <typename DT, typename MT> bool SparseMatrixCOO<DT, MT>::allocateSpace(bool onDevice) {
+    assert(this->data == nullptr && this->rowIdxs == nullptr && this->colIdxs == nullptr);
+    this->rowIdxs = allocateBuffer<MT>(this->numNonZero, onDevice);
+    this->colIdxs = allocateBuffer<MT>(this->numNonZero, onDevice);
+    this->data = allocateBuffer<DT>(this->numNonZero, onDevice);
+    if (onDevice) this->rowBoundsWorkspace = allocateBuffer<MT>((size_t)this->numRows + 1, true);
+    this->onDevice = onDevice;
+    return true;
+}
+
+template <typename DT, typename MT> SparseMatrixCOO<DT, MT> *SparseMatrixCOO<DT, MT>::copy2Device() {
+    assert(!this->onDevice && this->data != nullptr);
+    auto *d = new SparseMatrixCOO<DT, MT>(this->numRows, this->numCols, this->numNonZero, true);
+    copyBuffer(d->rowIdxs, true, this->rowIdxs, false, (size_t)this->numNonZero * sizeof(MT));
+    copyBuffer(d->colIdxs, true, this->colIdxs, false, (size_t)this->numNonZero * sizeof(MT));
+    copyBuffer(d->data, true, this->data, false, (size_t)this->numNonZero * sizeof(DT));
+    return d;
+}
+
+template <typename DT, typename MT> DenseMatrix<DT, MT> *SparseMatrixCOO<DT, MT>::toDense() {
+    assert(!this->onDevice);
+    auto *dm = new DenseMatrix<DT, MT>(this->numRows, this->numCols, false);
+    for (size_t i = 0; i < this->numNonZero; ++i)
+        dm->data[RowMjIdx(this->rowIdxs[i], this->colIdxs[i], this->numCols)] = this->data[i];
+    return dm;
+}
+
+template <typename DT, typename MT> bool SparseMatrixCOO<DT, MT>::isRowSorted() const {
+    assert(!this->onDevice);
+    for (size_t i = 1; i < this->numNonZero; ++i)
+        if (this->rowIdxs[i] < this->rowIdxs[i - 1]) return false;
+    return true;
+}
+
+template class SparseMatrixCOO<float, uint32_t>;
+template class SparseMatrixCOO<double, uint32_t>;
+
+}  // namespace cuspmm

@@ -1,0 +1,76 @@
+#include "formats/sparse_csr.hpp"
+
+namespace cuspmm {
+
+template <typename DT, typename MT> SparseMatrixCSR<DT, MT>::SparseMatrixCSR(std::string filePath) {
+    std::ifstream in(filePath);
+    if (!in.is_open()) {
+        std::cerr << "File " << filePath << " doesn't exist!" << std::endl;
+        throw std::runtime_error("cannot open " + filePath);
+    }
+    in >> this->numRows >> this->numCols >> this->numNonZero;
+    this->allocateSpace(false);
+    // three whitespace-separated arrays; the text format puts one per line but only the counts matter
+    for (size_t i = 0; i <= this->numRows; ++i) in >> this->rowPtrs[i];
+    for (size_t i = 0; i < this->numNonZero; ++i) in >> this->colIdxs[i];
+    for (size_t i = 0; i < this->numNonZero; ++i) in >> this->data[i];
+    if (in.fail()) throw std::runtime_error(filePath + ": truncated or malformed .csr file");
+}
+
+template <typename DT, typename MT>
+SparseMatrixCSR<DT, MT>::SparseMatrixCSR(MT numRows, MT numCols, MT numNonZero, bool onDevice) {
+    this->numRows = numRows;
+    this->numCols = numCols;
+    this->numNonZero = numNonZero;
+    this->allocateSpace(onDevice);
+}
+
+template <typename DT, typename MT> SparseMatrixCSR<DT, MT>::~SparseMatrixCSR() {
+    releaseBuffer(this->rowPtrs, this->onDevice);
+    releaseBuffer(this->colIdxs, this->onDevice);
+    releaseBuffer(this->data, this->onDevice);
+}
+
+template <typename DT, typename MT> bool SparseMatrixCSR<DT, MT>::allocateSpace(bool onDevice) {
+    assert(this->data == nullptr && this->rowPtrs == nullptr && this->colIdxs == nullptr);
+    this->rowPtrs = allocateBuffer<MT>((size_t)this->numRows + 1, onDevice);
+    this->colIdxs = allocateBuffer<MT>(this->numNonZero, onDevice);
+    this->data = allocateBuffer<DT>(this->numNonZero, onDevice);
+    this->onDevice = onDevice;
+    return true;
+}
+
+template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT, MT>::copy2Device() {
+    assert(!this->onDevice && this->rowPtrs != nullptr);
+    auto *d = new SparseMatrixCSR<DT, MT>(this->numRows, this->numCols, this->numNonZero, true);
+    copyBuffer(d->rowPtrs, true, this->rowPtrs, false, ((size_t)this->numRows + 1) * sizeof(MT));
+    copyBuffer(d->colIdxs, true, this->colIdxs, false, (size_t)this->numNonZero * sizeof(MT));
+    copyBuffer(d->data, true, this->data, false, (size_t)this->numNonZero * sizeof(DT));
+    return d;
+}
+
+template <typename DT, typename MT> DenseMatrix<DT, MT> *SparseMatrixCSR<DT, MT>::toDense() {
+    assert(!this->onDevice);
+    auto *dm = new DenseMatrix<DT, MT>(this->numRows, this->numCols, false);
+    for (MT r = 0; r < this->numRows; ++r)
+        for (MT i = this->rowPtrs[r]; i < this->rowPtrs[r + 1]; ++i)
+            dm->data[RowMjIdx(r, this->colIdxs[i], this->numCols)] = this->data[i];
+    return dm;
+}
+
+template <typename DT, typename MT> std::ostream &operator<<(std::ostream &out, SparseMatrixCSR<DT, MT> &m) {
+    out << m.numRows << ' ' << m.numCols << ' ' << m.numNonZero << '\n';
+    for (size_t i = 0; i <= m.numRows; ++i) out << m.rowPtrs[i] << (i == m.numRows ? '\n' : ' ');
+    for (size_t i = 0; i < m.numNonZero; ++i) out << m.colIdxs[i] << ' ';
+    out << '\n';
+    for (size_t i = 0; i < m.numNonZero; ++i) out << m.data[i] << ' ';
+    out << '\n';
+    return out;
+}
+
+template class SparseMatrixCSR<float, uint32_t>;
+template class SparseMatrixCSR<double, uint32_t>;
+template std::ostream &operator<<(std::ostream &, SparseMatrixCSR<float, uint32_t> &);
+template std::ostream &operator<<(std::ostream &, SparseMatrixCSR<double, uint32_t> &);
+
+}  // namespace cuspmm

@@ -1,0 +1,56 @@
+// COO: sequential CPU engine (kernel 0) and the HIP wrapper.
+#include "engine/engine_coo.hpp"
+#include "engine/wrapper_common.hpp"
+
+namespace cuspmm {
+
+// Kernel 0: every entry adds value * B[col, :] into C[row, :] in storage order, in DT
+// (/root/reference/src/spmm/coo/spmm_coo.cpp:16-24).  C arrives zero-filled.
+template <typename DT, typename MT, typename AccT>
+DenseMatrix<DT, MT> *spmmCOOCpu(SparseMatrixCOO<DT, MT> *ma, DenseMatrix<DT, MT> *mb, DenseMatrix<DT, MT> *mc) {
+    assert(!ma->onDevice && !mb->onDevice && !mc->onDevice);
+    mb->toOrdering(ORDERING::ROW_MAJOR);
+    const size_t n = mb->numCols;
+    for (size_t i = 0; i < ma->numNonZero; ++i) {
+        const DT v = ma->data[i];
+        const DT *brow = mb->data + (size_t)ma->colIdxs[i] * n;
+        DT *crow = mc->data + (size_t)ma->rowIdxs[i] * n;
+        for (size_t j = 0; j < n; ++j) {
+            const DT prod = v * brow[j];
+            crow[j] += prod;
+        }
+    }
+    return mc;
+}
+
+template <typename DT, typename MT, typename AccT>
+DenseMatrix<DT, MT> *spmmCOOWrapper(int kernelNum, SparseMatrixCOO<DT, MT> *a, DenseMatrix<DT, MT> *b,
+                                    DenseMatrix<DT, MT> *ref) {
+    if constexpr (!std::is_same_v<DT, float>) {
+        throw std::runtime_error("Not implemented");
+    } else {
+        assert(a->onDevice && b->onDevice);
+        b->toOrdering(ORDERING::ROW_MAJOR);
+        const double n = b->numCols;
+        const WrapperShape shape{"COO", a->numRows, a->numCols, a->numNonZero, 2.0 * a->numNonZero * n,
+                                 a->numNonZero * 12.0 + a->numCols * n * 4 + a->numRows * n * 4};
+        const int acc = accModeOf<AccT>();
+        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
+            return mispmm_coo_f32(nullptr, a->numRows, a->numCols, a->numNonZero, a->rowIdxs, a->colIdxs, a->data, b->data,
+                                  b->numCols, b->numCols, c, ldc, a->rowBoundsWorkspace, kernelNum, acc);
+        });
+    }
+}
+
+#define CUSPMM_INST(DT)                                                                                              \
+    template DenseMatrix<DT, uint32_t> *spmmCOOCpu<DT, uint32_t, double>(SparseMatrixCOO<DT, uint32_t> *,           \
+                                                                         DenseMatrix<DT, uint32_t> *,               \
+                                                                         DenseMatrix<DT, uint32_t> *);              \
+    template DenseMatrix<DT, uint32_t> *spmmCOOWrapper<DT, uint32_t, double>(int, SparseMatrixCOO<DT, uint32_t> *,  \
+                                                                             DenseMatrix<DT, uint32_t> *,           \
+                                                                             DenseMatrix<DT, uint32_t> *);
+CUSPMM_INST(float)
+CUSPMM_INST(double)
+#undef CUSPMM_INST
+
+}  // namespace cuspmm

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_coo_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _i, _i]),
+    "mispmm_vendor_spmm_f32": (_i, [_vp, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32,
+                                    _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mispmm_dense_transpose_f32": (_i, [_vp, _u32, _u32, _vp, _vp]),
     "mispmm_f32_to_bf16": (_i, [_vp, _sz, _vp, _vp]),
     "mispmm_bf16_to_f32": (_i, [_vp, _sz, _vp, _vp]),

@@ -180,6 +180,19 @@ int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz,
                    uint32_t ldc, uint32_t *rowPtrs_workspace, int kernel, int acc_mode);
 #define MISPMM_COO_NUM_KERNELS 1
 
+/* ------------------------------------------------------- vendor cross-check */
+/* rocSPARSE generic SpMM (alpha 1, beta 0, fp32) into C, timed as prolog (handle, descriptors,
+ * buffer, preprocess) / kernel (compute + sync) / epilog (teardown), all in microseconds.
+ * Replaces cusparseTest (src/engine/cusparse.cu:9-57; algorithms chosen like
+ * sparse_csr.cu:182-185 / sparse_coo.cu:97-100: CSR row split, COO segmented).  Synchronous and
+ * allocating: not for graph capture.  For CSR ptrs_or_rows = rowPtrs, for COO = rowIdxs, for BSR
+ * = blockRowPtrs with nnz = numBlocks and square blocks of block_dim (ignored otherwise). */
+enum mispmm_vendor_format { MISPMM_VENDOR_CSR = 0, MISPMM_VENDOR_COO = 1, MISPMM_VENDOR_BSR = 2 };
+int mispmm_vendor_spmm_f32(mispmm_stream_t stream, int format, uint32_t M, uint32_t K, uint32_t nnz, uint32_t block_dim,
+                           const uint32_t *ptrs_or_rows, const uint32_t *cols, const float *vals, const float *B,
+                           uint32_t N, uint32_t ldb, float *C, uint32_t ldc, double *pro_us, double *kernel_us,
+                           double *epi_us);
+
 /* ------------------------------------------------------------ dense helpers */
 /* dst[cols x rows] = transpose(src[rows x cols]); both dense row-major buffers.
  * Replaces the host round trip of DenseMatrix::toOrdering (dense.cu:139-191). */
