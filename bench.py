@@ -248,8 +248,9 @@ def run_multi(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
-        if world == 1:
+    force = os.environ.get("MISPMM_FORCE_DIST") == "1"    # rehearse the RCCL path with a single rank
+    if args.gpus > 1 or world > 1 or force:
+        if world == 1 and not force:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         run_multi(args)
     else:

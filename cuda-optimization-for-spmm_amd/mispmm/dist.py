@@ -80,9 +80,13 @@ class ShardedCsrSpmm:
             done.record(self.compute_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(done)
-                self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf], self.ring[buf], async_op=True)
+                self.pending[buf] = dist.all_gather_into_tensor(self._flat(buf), self.ring[buf], async_op=True)
         else:
-            self.pending[buf] = dist.all_gather_into_tensor(self.gathered[buf], self.ring[buf], async_op=True)
+            self.pending[buf] = dist.all_gather_into_tensor(self._flat(buf), self.ring[buf], async_op=True)
+
+    def _flat(self, buf):
+        # all_gather_into_tensor wants the output as the inputs concatenated along dim 0
+        return self.gathered[buf].view(self.world * self.bucket, self.slab_rows, self.n)
 
     def _wait(self, buf, on_stream=None):
         w = self.pending[buf]
