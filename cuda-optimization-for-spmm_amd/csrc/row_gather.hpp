@@ -1,0 +1,179 @@
+// The row-group gather kernel shared by CSR (kernel 5), ELL and COO: G lanes own one C row, lane i
+// fetches entry i of the row's current G-entry chunk, B-row byte offsets are broadcast by lane
+// shuffle, up to 16 B-row reads per lane are in flight as dropped-or-live buffer loads, products
+// are summed in storage order, and C leaves through write-through stores.  Workgroups are laid
+// over the 8 XCDs as a P x Q grid of (row part, column part) so each XCD's L2 holds 1/Q of the
+// width of the B rows that 1/P of the matrix rows touch (see k5 in spmm_csr.hip for the
+// traffic model).  `Rows` says where a row's entries live:
+//   CsrRows  entries [rowPtrs[r], rowPtrs[r+1])            (also a COO whose row bounds were built)
+//   EllRows  entries [r * width, (r + 1) * width), column 0xFFFFFFFF = padding (dropped)
+#pragma once
+#include <cstdio>
+#include <cstdlib>
+
+#include "spmm_common.hpp"
+
+namespace mispmm {
+
+struct CsrRows {
+    const uint32_t *rowPtrs;
+    static constexpr bool kPadded = false;
+    __device__ __forceinline__ void extent(uint32_t row, size_t &base, uint32_t &len) const {
+        const uint32_t s = rowPtrs[row];
+        base = s;
+        len = rowPtrs[row + 1] - s;
+    }
+};
+
+struct EllRows {
+    uint32_t width;
+    static constexpr bool kPadded = true;
+    __device__ __forceinline__ void extent(uint32_t row, size_t &base, uint32_t &len) const {
+        base = static_cast<size_t>(row) * width;
+        len = width;
+    }
+};
+
+template <int G, int VEC, class Acc, bool SC1, class Rows>
+__global__ __launch_bounds__(256) void row_gather_kernel(uint32_t M, Rows rows, const uint32_t *__restrict__ colIdxs,
+                                                         const float *__restrict__ vals, const float *__restrict__ B,
+                                                         uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
+                                                         uint32_t c_bytes, uint32_t ldc, uint32_t rb_chunk, uint32_t log2p,
+                                                         uint32_t cols_per_part) {
+    constexpr int GROUPS = 256 / G;
+    constexpr int U = 16;  // every B read of a <= 16-entry row is in flight at once
+    using vec_t = typename VecOf<VEC>::type;
+    const uint32_t lane = threadIdx.x % G;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t p = xcd & ((1u << log2p) - 1u), q = xcd >> log2p;
+    const uint32_t row = (p * rb_chunk + slot) * GROUPS + threadIdx.x / G;
+    const uint32_t col0 = q * cols_per_part + blockIdx.y * (G * VEC) + lane * VEC;
+    const bool row_ok = row < M;
+    const bool col_ok = col0 < min(N, (q + 1) * cols_per_part);
+    size_t row_base = 0;
+    uint32_t row_len = 0;
+    if (row_ok) rows.extent(row, row_base, row_len);
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;  // lanes past the column part never fetch
+
+    for (uint32_t base = 0; base < row_len; base += G) {
+        const uint32_t cnt = min(static_cast<uint32_t>(G), row_len - base);
+        const size_t mine = row_base + base + min(lane, cnt - 1);
+        const uint32_t my_col = colIdxs[mine];
+        float my_val = vals[mine];
+        uint32_t my_off = my_col * (ldb * 4u);
+        if constexpr (Rows::kPadded) {  // padding becomes a dropped load with a zero coefficient
+            if (my_col == 0xFFFFFFFFu) {
+                my_off = kDropLoad;
+                my_val = 0.f;
+            }
+        }
+        for (uint32_t j = 0; j < cnt; j += U) {
+            vec_t bv[U];
+            float av[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t src = (j + u) & (G - 1);
+                const uint32_t off = __shfl(my_off, src, G);
+                const float a = __shfl(my_val, src, G);
+                bool live = j + u < cnt;
+                if constexpr (Rows::kPadded) live = live && off != kDropLoad;
+                av[u] = live ? a : 0.f;
+                bv[u] = buffer_load_vec<VEC>(rsrc, live ? off + lane_off : kDropLoad, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // dropped slots add 0 * 0 = +0 to a sum that is never -0: exact no-op
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
+            }
+        }
+    }
+    if (row_ok && col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        if constexpr (SC1) {
+            buffer_store_vec_sc1<VEC>(make_rsrc(C, c_bytes), (row * ldc + col0) * 4u, out);
+        } else {
+            store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+struct RowGatherArgs {
+    hipStream_t stream;
+    uint32_t M, K;
+    const uint32_t *colIdxs;
+    const float *vals, *B;
+    uint32_t N, ldb;
+    float *C;
+    uint32_t ldc;
+};
+
+// P x Q XCD grid and the C store flavour.  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
+// the defaults (measurement aid; results never depend on them).
+struct XcdTiling {
+    uint32_t log2p, q;
+    bool sc1;
+};
+
+inline XcdTiling xcd_tiling(uint32_t N, int vec) {
+    // default: 4 row parts x 2 column parts once a half-width part still fills 32-lane row groups
+    // (measured on n4c6-b13 x 128: 4.26 us vs 4.48 us for 8 x 1); otherwise 8 x 1
+    XcdTiling t{3u, 1u, true};
+    if (N >= 128 && N % (2u * 32u * vec) == 0) t = XcdTiling{2u, 2u, true};
+    if (const char *e = getenv("MISPMM_CSR_TILING")) {
+        unsigned pp = 8, qq = 1;
+        if (sscanf(e, "%u,%u", &pp, &qq) == 2 && pp * qq == 8 && (pp == 1 || pp == 2 || pp == 4 || pp == 8)) {
+            t.log2p = pp == 1 ? 0u : pp == 2 ? 1u : pp == 4 ? 2u : 3u;
+            t.q = qq;
+        }
+    }
+    // a column part must hold at least one 8-lane group of whole vectors
+    while (t.q > 1 && (N % t.q != 0 || (N / t.q) % (8u * vec) != 0)) {
+        t.q >>= 1;
+        ++t.log2p;
+    }
+    if (const char *e = getenv("MISPMM_STORE_SC1")) t.sc1 = e[0] != '0';
+    return t;
+}
+
+template <int G, int VEC, class Acc, class Rows>
+void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
+    const uint32_t cols_per_part = a.N / t.q;
+    const uint32_t rb = ceil_div(a.M, 256 / G);
+    const uint32_t rb_chunk = ceil_div(rb, 1u << t.log2p);
+    dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
+    if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows>), grid, dim3(256), 0, a.stream, a.M, rows, a.colIdxs,
+                           a.vals, a.B, b_bytes, a.N, a.ldb, a.C, static_cast<uint32_t>(c_bytes), a.ldc, rb_chunk, t.log2p,
+                           cols_per_part);
+    else
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows>), grid, dim3(256), 0, a.stream, a.M, rows, a.colIdxs,
+                           a.vals, a.B, b_bytes, a.N, a.ldb, a.C, 0u, a.ldc, rb_chunk, t.log2p, cols_per_part);
+}
+
+// needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check
+template <class Acc, class Rows>
+void launch_row_gather_auto(const RowGatherArgs &a, const Rows &rows, int vec) {
+    const XcdTiling t = xcd_tiling(a.N, vec);
+    const int g = pick_group(a.N / t.q, vec);
+#define MISPMM_RG_CASE(GG, VV)                                     \
+    if (g == GG && vec == VV) {                                    \
+        launch_row_gather<GG, VV, Acc, Rows>(a, rows, t);          \
+        return;                                                    \
+    }
+    MISPMM_RG_CASE(8, 4) MISPMM_RG_CASE(16, 4) MISPMM_RG_CASE(32, 4) MISPMM_RG_CASE(64, 4)
+    MISPMM_RG_CASE(8, 2) MISPMM_RG_CASE(16, 2) MISPMM_RG_CASE(32, 2) MISPMM_RG_CASE(64, 2)
+    MISPMM_RG_CASE(8, 1) MISPMM_RG_CASE(16, 1) MISPMM_RG_CASE(32, 1) MISPMM_RG_CASE(64, 1)
+#undef MISPMM_RG_CASE
+}
+
+}  // namespace mispmm

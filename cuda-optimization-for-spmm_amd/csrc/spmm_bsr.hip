@@ -12,7 +12,8 @@
 //             and the k slots are mapped to ascending block columns, so the result equals the
 //             FAST VALU kernel's bit for bit.
 //   bsr_mfma_bf16  16x16 bf16 blocks on v_mfma_f32_16x16x32_bf16, two blocks per instruction
-//             (K = 32), fp32 accumulate, B transposed into operand order in registers (v_perm).
+//             (K = 32), fp32 accumulate, B transposed into operand order in registers (v_perm);
+//             the 4 waves of a workgroup split a block row's pairs and reduce through LDS.
 // Output columns of a 64-wide super-tile are interleaved over the 4 accumulator tiles
 // (tile t, lane column c <-> column 4c + t), so B rows are read and C rows written as whole
 // 16-byte (fp32) / 8-byte (bf16) vectors.
@@ -105,14 +106,22 @@ __global__ __launch_bounds__(256) void bsr_valu(uint32_t M, uint32_t bR, uint32_
 // Lane l = (c = l & 15, g = l >> 4).  MFMA 16x16x4: A operand lane holds A[i = c][k = g],
 // B operand lane holds B[k = g][j = c]; D register r of lane l is D[row 4g + r][col c].
 // Step s of a block uses block columns 4s + g, so k runs over ascending columns.
+// The loop is software-pipelined two blocks deep: while block b is on the matrix pipe the A/B
+// fragments of b + 1 are in flight and the block column of b + 2 is being fetched -- without it a
+// wave spends a full index -> B-row round trip per block (measured 100 us vs the 14 us MFMA floor).
+struct F32Frag {
+    float a[4];
+    f32x4_t bv[4];
+};
+
 __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                     const uint32_t *__restrict__ blockColIdxs,
                                                     const float *__restrict__ blocks, const float *__restrict__ B,
                                                     uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
-                                                    uint32_t ldc) {
+                                                    uint32_t ldc, uint32_t xcd_chunk) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t item = blockIdx.x * 4 + wave;
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk) * 4 + wave;
     if (item >= Mb * nST) return;  // wave-uniform
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
@@ -125,20 +134,33 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
-    for (uint32_t b = bs; b < be; ++b) {
-        const uint32_t brow0 = blockColIdxs[b] * 16u;
-        const float *ablk = blocks + static_cast<size_t>(b) * 256u + c * 16u + g;
-        float a[4];
-        f32x4_t bv[4];
+    if (bs < be) {
+        const uint32_t last = be - 1;
+        auto load_frag = [&](uint32_t b, uint32_t bcol, F32Frag &f) {  // b may run past `last`: clamped, unused
+            const float *ablk = blocks + static_cast<size_t>(min(b, last)) * 256u + c * 16u + g;
+            const uint32_t voff = b <= last ? lane_off : kDropLoad;  // the prefetch past the row fetches nothing
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a[s] = ablk[4 * s];
-            bv[s] = buffer_load_vec<4>(rsrc, lane_off, (brow0 + 4 * s + g) * ldb4);
-        }
+            for (int s = 0; s < 4; ++s) {
+                f.a[s] = ablk[4 * s];
+                // the lane-dependent row (4s + g) rides in voffset: a non-uniform soffset would make
+                // hipcc wrap every load in a waterfall loop
+                f.bv[s] = buffer_load_vec<4>(rsrc, voff + (4 * s + g) * ldb4, bcol * 16u * ldb4);
+            }
+        };
+        uint32_t col_next = blockColIdxs[min(bs + 1, last)];
+        F32Frag cur;
+        load_frag(bs, blockColIdxs[bs], cur);
+        for (uint32_t b = bs; b < be; ++b) {
+            const uint32_t col_next2 = blockColIdxs[min(b + 2, last)];
+            F32Frag nxt;
+            load_frag(b + 1, col_next, nxt);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bv[s][t], acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[s], cur.bv[s][t], acc[t], 0, 0, 0);
+            }
+            cur = nxt;
+            col_next = col_next2;
         }
     }
     if (ncol < N) {
@@ -151,21 +173,30 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
 }
 
 // --------------------------------------------------------------------------------- bsr_mfma_bf16
-// Same work split.  MFMA 16x16x32 bf16: lane (c, g) holds A[i = c][k = 8g .. 8g+7] and
-// B[k = 8g .. 8g+7][j = c].  k slots 0..15 are the 16 columns of block b, slots 16..31 those of
-// block b + 1 (zero when the block row has an odd block left).  A lane reads, for each of its 8 k
-// rows, the 4 consecutive bf16 of columns 4c .. 4c+3 (8 bytes, one per accumulator tile) and
-// regroups them per tile with v_perm_b32: the transpose B needs, done in registers.
+// One WORKGROUP per (block row, 64-column super-tile); its 4 waves split the block row's block
+// pairs round-robin (pair p -> wave p % 4), each keeps a partial 16 x 64 fp32 tile, and the partials
+// are summed through LDS in fixed wave order (deterministic) before the store.  MFMA 16x16x32 bf16:
+// lane (c, g) holds A[i = c][k = 8g .. 8g+7] and B[k = 8g .. 8g+7][j = c].  k slots 0..15 are the 16
+// columns of the pair's first block, slots 16..31 those of its second block (zero when an odd block
+// is left over).  A lane reads, for each of its 8 k rows, the 4 consecutive bf16 of columns
+// 4c .. 4c+3 (8 bytes, one per accumulator tile) and regroups them per tile with v_perm_b32: the
+// transpose B needs, done in registers.  Same two-deep software pipeline as the fp32 kernel.
+struct Bf16Frag {
+    u32x4_t araw;
+    u32x2_t braw[8];
+};
+
 template <bool C_BF16>
 __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
                                                      uint32_t b_bytes, uint32_t N, uint32_t ldb, void *__restrict__ Cv,
-                                                     uint32_t ldc) {
+                                                     uint32_t ldc, uint32_t xcd_chunk) {
+    __shared__ f32x4_t partial[3][4][64];  // waves 1..3, 4 tiles, one vector per lane (12 KiB)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t item = blockIdx.x * 4 + wave;
-    if (item >= Mb * nST) return;
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk);
+    if (item >= Mb * nST) return;  // workgroup-uniform, before any barrier
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
     const uint32_t ncol = st * 64 + c * 4;
@@ -173,37 +204,65 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
     const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
     const uint32_t ldb2 = ldb * 2u;
     const uint32_t khalf = (g & 1) * 8u;  // first block column of this lane's 8 k slots
+    const uint32_t second = g >> 1;       // lanes g = 2,3 take the second block of the pair
 
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
-    for (uint32_t b0 = bs; b0 < be; b0 += 2) {
-        const uint32_t b = b0 + (g >> 1);      // lanes g = 2,3 take the second block of the pair
-        const bool have = b < be;
-        const uint32_t bsafe = have ? b : b0;  // keep the index loads in range
-        const uint32_t brow0 = blockColIdxs[bsafe] * 16u + khalf;
-        u32x4_t araw = *reinterpret_cast<const u32x4_t *>(blocks + static_cast<size_t>(bsafe) * 256u + c * 16u + khalf);
-        if (!have) araw = u32x4_t{0u, 0u, 0u, 0u};
-        u32x2_t braw[8];
+    const uint32_t npairs = (be - bs + 1) / 2;
+    if (wave < npairs) {
+        const uint32_t last = be - 1;
+        auto block_of = [&](uint32_t pair) { return bs + 2 * pair + second; };
+        auto load_frag = [&](uint32_t pair, uint32_t bcol, Bf16Frag &f) {
+            const uint32_t b = block_of(pair);
+            const bool have = b <= last;  // false for the missing half of an odd pair and past the row
+            f.araw = *reinterpret_cast<const u32x4_t *>(blocks + static_cast<size_t>(min(b, last)) * 256u + c * 16u + khalf);
+            if (!have) f.araw = u32x4_t{0u, 0u, 0u, 0u};
+            // the block column differs between the two halves of the wave, so the whole row offset
+            // is per-lane (voffset); soffset stays 0
+            const uint32_t voff = have ? lane_off + (bcol * 16u + khalf) * ldb2 : kDropLoad;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, have ? lane_off : kDropLoad, (brow0 + e) * ldb2, 0);
-            braw[e] = __builtin_bit_cast(u32x2_t, r);
-        }
-        const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, araw);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            // tile t takes bf16 element t of every k row: dword t>>1, half t&1
-            u32x4_t packed;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t lo = braw[2 * p][t >> 1], hi = braw[2 * p + 1][t >> 1];
-                packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u)   // {hi.h1, lo.h1}
-                                    : __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+            for (int e = 0; e < 8; ++e) {
+                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + e * ldb2, 0, 0);
+                f.braw[e] = __builtin_bit_cast(u32x2_t, r);
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, packed), acc[t], 0, 0, 0);
+        };
+        uint32_t col_next = blockColIdxs[min(block_of(wave + 4), last)];
+        Bf16Frag cur;
+        load_frag(wave, blockColIdxs[min(block_of(wave), last)], cur);
+        for (uint32_t pair = wave; pair < npairs; pair += 4) {
+            const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 8), last)];
+            Bf16Frag nxt;
+            load_frag(pair + 4, col_next, nxt);
+            const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, cur.araw);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // tile t takes bf16 element t of every k row: dword t>>1, half t&1
+                u32x4_t packed;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t lo = cur.braw[2 * p][t >> 1], hi = cur.braw[2 * p + 1][t >> 1];
+                    packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u)   // {hi.h1, lo.h1}
+                                        : __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, packed), acc[t], 0, 0, 0);
+            }
+            cur = nxt;
+            col_next = col_next2;
         }
+    }
+    // fixed-order reduction of the four partial tiles: wave 0 adds waves 1, 2, 3 in that order
+    if (wave != 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) partial[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += partial[w][t][lane];
     }
     if (ncol < N) {
 #pragma unroll
@@ -298,9 +357,9 @@ extern "C" int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uin
     if (kernel == MISPMM_KERNEL_AUTO) kernel = (mfma_ok && acc_mode == MISPMM_ACC_FAST) ? 2 : 1;
     if (kernel == 2) {
         const uint32_t nST = ceil_div(N, 64u);
-        hipLaunchKernelGGL(bsr_mfma_f32, dim3(ceil_div(numBlockRows * nST, 4u)), dim3(256), 0, st, numBlockRows, nST,
-                           blockRowPtrs, blockColIdxs, blocks, B, static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u),
-                           N, ldb, C, ldc);
+        const XcdGrid xg = xcd_grid(ceil_div(numBlockRows * nST, 4u));
+        hipLaunchKernelGGL(bsr_mfma_f32, dim3(xg.grid), dim3(256), 0, st, numBlockRows, nST, blockRowPtrs, blockColIdxs,
+                           blocks, B, static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u), N, ldb, C, ldc, xg.chunk);
     } else {
         const BsrArgs a{st, numBlockRows, K, bR, bC, blockRowPtrs, blockColIdxs, blocks, B, N, ldb, C, ldc};
         const int vec = pick_vec(B, ldb, C, ldc, N);
@@ -323,14 +382,15 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     if (!mfma_shape_ok(K, N, ldb, ldc, B, C, blocks, 2) || (!c_bf16 && !aligned16(C)))
         return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: N/ldb/ldc must be multiples of 4 and operands vector-aligned");
     const uint32_t nST = ceil_div(N, 64u);
-    dim3 grid(ceil_div(numBlockRows * nST, 4u));
+    const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, super-tile)
+    dim3 grid(xg.grid);
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
     if (c_bf16)
         hipLaunchKernelGGL(bsr_mfma_bf16<true>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc);
+                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
     else
         hipLaunchKernelGGL(bsr_mfma_bf16<false>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc);
+                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

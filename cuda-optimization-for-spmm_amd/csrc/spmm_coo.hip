@@ -8,7 +8,7 @@
 // dropped-or-live buffer loads, fp32 products summed in storage order (REFERENCE mode = the
 // rounding sequence of spmmCOOCpu, spmm_coo.cpp:16-24).  No atomics, deterministic.
 // Without a workspace each row group finds its range by binary search instead.
-#include "spmm_common.hpp"
+#include "row_gather.hpp"
 
 namespace mispmm {
 
@@ -167,6 +167,14 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     }
     const CooArgs a{st, M, K, nnz, rowIdxs, rowPtrs_workspace, colIdxs, vals, B, N, ldb, C, ldc};
     const int vec = pick_vec(B, ldb, C, ldc, N);
+    if (rowPtrs_workspace && static_cast<uint64_t>(K) * ldb * 4u <= 0x7FFFFFFFull) {
+        // with its row bounds materialised a sorted COO is a CSR: same kernel, same order of sums
+        const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc};
+        if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefF32>(ga, CsrRows{rowPtrs_workspace}, vec);
+        else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs_workspace}, vec);
+        MISPMM_LAUNCH_CHECK();
+        return MISPMM_OK;
+    }
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_coo_v<AccRefF32>(a, vec);
     else launch_coo_v<AccFast>(a, vec);
     MISPMM_LAUNCH_CHECK();

@@ -14,10 +14,7 @@
 //   k4  k3 with two rows interleaved per wave (half the waves, twice the loads in flight)
 // Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
-#include <cstdio>
-#include <cstdlib>
-
-#include "spmm_common.hpp"
+#include "row_gather.hpp"
 
 namespace mispmm {
 
@@ -146,74 +143,11 @@ __global__ __launch_bounds__(256) void csr_k1(uint32_t M, const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------ k5
-// k1's row groups with a 2-D XCD tiling.  The 8 XCDs form a P x Q grid (P * Q = 8): XCD x works on
-// row part x % P and column part x / P, so its L2 holds 1/Q of the width of the B rows that 1/P of
-// the matrix rows touch.  What leaves the L2s is  (sum over row parts of distinct B rows) * N*4
-// + Q * bytes(A):  fewer, larger row parts share more B rows, at the price of re-reading A once per
-// column part and of narrower (N/Q-column) row segments.  P = 8, Q = 1 is k1.  SC1 selects
-// write-through C stores.
-template <int G, int VEC, class Acc, bool SC1>
-__global__ __launch_bounds__(256) void csr_k5(uint32_t M, const uint32_t *__restrict__ rowPtrs,
-                                              const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
-                                              const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
-                                              float *__restrict__ C, uint32_t c_bytes, uint32_t ldc, uint32_t rb_chunk,
-                                              uint32_t log2p, uint32_t cols_per_part) {
-    constexpr int GROUPS = 256 / G;
-    constexpr int U = 16;  // every B read of a <= 16-entry row is in flight at once
-    using vec_t = typename VecOf<VEC>::type;
-    const uint32_t lane = threadIdx.x % G;
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t p = xcd & ((1u << log2p) - 1u), q = xcd >> log2p;
-    const uint32_t row = (p * rb_chunk + slot) * GROUPS + threadIdx.x / G;
-    const uint32_t col0 = q * cols_per_part + blockIdx.y * (G * VEC) + lane * VEC;
-    const bool row_ok = row < M;
-    const bool col_ok = col0 < min(N, (q + 1) * cols_per_part);
-    uint32_t start = 0, end = 0;
-    if (row_ok) {
-        start = rowPtrs[row];
-        end = rowPtrs[row + 1];
-    }
-    typename Acc::T acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0;
-    const rsrc_t rsrc = make_rsrc(B, b_bytes);
-    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;
-
-    for (uint32_t base = start; base < end; base += G) {
-        const uint32_t cnt = min(static_cast<uint32_t>(G), end - base);
-        const uint32_t mine = base + min(lane, cnt - 1);
-        const uint32_t my_off = colIdxs[mine] * (ldb * 4u);
-        const float my_val = vals[mine];
-        for (uint32_t j = 0; j < cnt; j += U) {
-            vec_t bv[U];
-            float av[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t src = (j + u) & (G - 1);
-                const uint32_t off = __shfl(my_off, src, G);
-                const float a = __shfl(my_val, src, G);
-                av[u] = (j + u < cnt) ? a : 0.f;
-                bv[u] = buffer_load_vec<VEC>(rsrc, (j + u < cnt) ? off + lane_off : kDropLoad, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[u], vec_get<VEC>(bv[u], v));
-            }
-        }
-    }
-    if (row_ok && col_ok) {
-        vec_t out;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
-        if constexpr (SC1) {
-            buffer_store_vec_sc1<VEC>(make_rsrc(C, c_bytes), (row * ldc + col0) * 4u, out);
-        } else {
-            store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
-        }
-    }
-}
+// k1's row groups with a 2-D XCD tiling and write-through C stores: row_gather.hpp (shared with ELL
+// and COO).  The 8 XCDs form a P x Q grid (P * Q = 8): XCD x works on row part x % P and column
+// part x / P.  What leaves the L2s is  (sum over row parts of distinct B rows) * N*4 + Q * bytes(A):
+// fewer, larger row parts share more B rows, at the price of re-reading A once per column part and
+// of narrower (N/Q-column) row segments.  P = 8, Q = 1 is k1's traffic.
 
 // ------------------------------------------------------------------------------------------ k2
 // One workgroup = 256/G consecutive rows.  Their (col, val) pairs are one contiguous range of the
@@ -461,70 +395,14 @@ static void launch_wave(const CsrArgs &a) {
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }
 
-// k5 tuning: P x Q XCD grid and the C store flavour.  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1
-// override the defaults (measurement aid; results never depend on them).
-struct K5Tuning {
-    uint32_t log2p, q;
-    bool sc1;
-};
-static K5Tuning k5_tuning(uint32_t N, int vec) {
-    // default: 4 row parts x 2 column parts once a half-width part still fills 32-lane row groups
-    // (measured on n4c6-b13 x 128: 4.26 us vs 4.48 us for 8 x 1); otherwise 8 x 1
-    K5Tuning t{3u, 1u, true};
-    if (N >= 128 && N % (2u * 32u * vec) == 0) t = K5Tuning{2u, 2u, true};
-    if (const char *e = getenv("MISPMM_CSR_TILING")) {
-        unsigned pp = 8, qq = 1;
-        if (sscanf(e, "%u,%u", &pp, &qq) == 2 && pp * qq == 8 && (pp == 1 || pp == 2 || pp == 4 || pp == 8)) {
-            t.log2p = pp == 1 ? 0u : pp == 2 ? 1u : pp == 4 ? 2u : 3u;
-            t.q = qq;
-        }
-    }
-    // a column part must hold at least one 8-lane group of whole vectors
-    while (t.q > 1 && (N % t.q != 0 || (N / t.q) % (8u * vec) != 0)) {
-        t.q >>= 1;
-        ++t.log2p;
-    }
-    if (const char *e = getenv("MISPMM_STORE_SC1")) t.sc1 = e[0] != '0';
-    return t;
-}
-
-template <int G, int VEC, class Acc>
-static void launch_k5(const CsrArgs &a, const K5Tuning &t) {
-    const uint32_t cols_per_part = a.N / t.q;
-    const uint32_t rb = ceil_div(a.M, 256 / G);
-    const uint32_t rb_chunk = ceil_div(rb, 1u << t.log2p);
-    dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
-    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
-    const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
-    if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((csr_k5<G, VEC, Acc, true>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals,
-                           a.B, b_bytes, a.N, a.ldb, a.C, static_cast<uint32_t>(c_bytes), a.ldc, rb_chunk, t.log2p,
-                           cols_per_part);
-    else
-        hipLaunchKernelGGL((csr_k5<G, VEC, Acc, false>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals,
-                           a.B, b_bytes, a.N, a.ldb, a.C, 0u, a.ldc, rb_chunk, t.log2p, cols_per_part);
-}
-
-template <int VEC, class Acc>
-static void launch_k5_g(const CsrArgs &a, const K5Tuning &t) {
-    switch (pick_group(a.N / t.q, VEC)) {
-        case 8: launch_k5<8, VEC, Acc>(a, t); break;
-        case 16: launch_k5<16, VEC, Acc>(a, t); break;
-        case 32: launch_k5<32, VEC, Acc>(a, t); break;
-        default: launch_k5<64, VEC, Acc>(a, t); break;
-    }
-}
-
 template <class Acc>
 static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     // buffer offsets are 32-bit and bit 31 marks a dropped load: a B of 2 GiB or more takes the
     // 64-bit-address kernel
     const bool wide = static_cast<uint64_t>(a.K) * a.ldb * 4u > 0x7FFFFFFFull;
     if (kernel == 5 && !wide) {
-        const K5Tuning t = k5_tuning(a.N, vec);
-        if (vec == 4) launch_k5_g<4, Acc>(a, t);
-        else if (vec == 2) launch_k5_g<2, Acc>(a, t);
-        else launch_k5_g<1, Acc>(a, t);
+        const RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc};
+        launch_row_gather_auto<Acc>(ga, CsrRows{a.rowPtrs}, vec);
         return;
     }
     if (kernel == 1 || kernel == 2 || kernel == 5 || wide) {
