@@ -146,6 +146,14 @@ def run_single(args):
 
     flops = datasets.spmm_flops(csr.nnz, n)
     abytes = datasets.csr_algorithmic_bytes(csr, n)
+    traffic = None     # PMC counters cannot be read from inside this process: committed rocprofv3 figure
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as f:
+            entry = json.load(f).get(f"{args.matrix}/{n}")
+        if entry and args.kernel in (0, 5):
+            traffic = entry["total_bytes"]
+    except OSError:
+        pass
     launch_s = ms.value * 1e-3 / args.steps
     achieved = abytes / launch_s / 1e9
     info = capi.device_info(0)
@@ -159,10 +167,10 @@ def run_single(args):
                    "kernel": args.kernel, "acc_mode": args.acc, "launch": args.launch, "device": info["name"]},
         "achieved_hbm_GBps": round(abytes * args.steps / wall / 1e9, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": abytes, "launch_us": round(launch_s * 1e6, 3),
                      "note": "launch_us = HIP-event time over the timed region / steps (includes inter-kernel gaps); "
-                             "PMC traffic: see profiles/"},
+                             "traffic = L2<->fabric bytes per launch from rocprofv3 PMC (profiles/r1/traffic.json)"},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(csr, b_host, args.cpu_seconds, c.cpu().numpy(), args.acc)
