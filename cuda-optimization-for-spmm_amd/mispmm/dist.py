@@ -11,11 +11,13 @@ few, large messages).
 The compute step is injectable so the partition / bucket / gather logic is exercised on CPU with
 the gloo backend (tests/test_dist_cpu.py); on a GPU the default is the HIP kernel via the C ABI.
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import formats, ops
+from . import capi, formats, ops
 
 
 def shard_bounds(row_ptrs, parts):
@@ -60,6 +62,10 @@ class ShardedCsrSpmm:
             self.comm_stream = torch.cuda.Stream(device=self.device)
         else:
             self.compute_stream = self.comm_stream = None
+        # One hipGraph per ring buffer holding a whole bucket of kernel launches (slots 0..bucket-1):
+        # a step is a few microseconds, so launching each from Python would be host-bound.
+        self.bucket_graphs = [None, None]
+        self.use_graphs = self.on_gpu and compute is None
 
     # -- the compute step ------------------------------------------------------------------------
     def _hip_compute(self, a, b, out):
@@ -99,7 +105,39 @@ class ShardedCsrSpmm:
             w.wait()
         self.pending[buf] = None
 
+    def _bucket_graph(self, buf):
+        if self.bucket_graphs[buf] is None:
+            l = capi.lib()
+            sp = ctypes.c_void_p(self.compute_stream.cuda_stream)
+            self.compute_stream.synchronize()
+            capi.check(l.mispmm_graph_begin(sp))
+            for slot in range(self.bucket):
+                self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
+            g = ctypes.c_void_p()
+            capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
+            self.bucket_graphs[buf] = g
+        return self.bucket_graphs[buf]
+
     def run(self, steps, gather=True):
+        done = 0
+        while done < steps:
+            i = self.step_count
+            buf, slot = (i // self.bucket) % 2, i % self.bucket
+            if self.use_graphs and self.rows and slot == 0 and steps - done >= self.bucket:
+                # a whole bucket at once: replay its graph, then hand the ring buffer to the collective
+                self._wait(buf, self.compute_stream)
+                capi.check(capi.lib().mispmm_graph_launch(self._bucket_graph(buf),
+                                                          ctypes.c_void_p(self.compute_stream.cuda_stream)))
+                self.step_count += self.bucket
+                done += self.bucket
+                if gather:
+                    self._gather(buf)
+                    self.last = (buf, self.bucket - 1)
+                continue
+            self._run_eager(1, gather)
+            done += 1
+
+    def _run_eager(self, steps, gather):
         for _ in range(steps):
             i = self.step_count
             buf, slot = (i // self.bucket) % 2, i % self.bucket
@@ -125,6 +163,12 @@ class ShardedCsrSpmm:
         if self.on_gpu:
             self.compute_stream.synchronize()
             self.comm_stream.synchronize()
+
+    def close(self):
+        for g in self.bucket_graphs:
+            if g is not None:
+                capi.check(capi.lib().mispmm_graph_destroy(g))
+        self.bucket_graphs = [None, None]
 
     # -- results ---------------------------------------------------------------------------------
     def gathered_c(self):

@@ -340,3 +340,44 @@ def test_bf16_conversion_round_to_nearest_even():
     back = ops.bf16_to_f32(bits).cpu().numpy()
     assert np.array_equal(back, synth.bf16_round(x))
     assert np.isnan(ops.bf16_to_f32(ops.f32_to_bf16(dev(np.array([np.nan], np.float32)))).cpu().numpy()[0])
+
+
+# --------------------------------------------------------------------------- > 2 GiB dense operand
+def test_wide_address_fallbacks_for_b_beyond_2gib(oracle):
+    """A B whose rows are 32 KiB apart spans 2.2 GiB: buffer offsets no longer fit, every format must
+    take its 64-bit-address kernel and still be bit-exact.  Only N = 8 columns are real data."""
+    k_rows, ldb, n = 70000, 8192, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 6 * 2 ** 30:
+        pytest.skip("needs ~2.3 GiB of device memory")
+    rng = np.random.default_rng(21)
+    lens = rng.integers(0, 40, size=300)
+    csr = random_csr(300, k_rows, lens, seed=22)
+    b = synth.dense_b(k_rows, n)
+    big = torch.zeros((k_rows, ldb), dtype=torch.float32, device="cuda")
+    bview = big[:, :n]
+    bview.copy_(dev(b))
+    assert bview.stride(0) * k_rows * 4 > 2 ** 31
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    a = ops.DeviceCSR.from_host(csr)
+    for kern in (0, 1, 3, 5):
+        assert np.array_equal(ops.spmm_csr(a, bview, kernel=kern).cpu().numpy(), ref), kern
+    coo = formats.csr_to_coo(csr)
+    ref32 = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, b)
+    for ws in (True, False):
+        assert np.array_equal(ops.spmm_coo(ops.DeviceCOO.from_host(coo), bview, workspace=ws).cpu().numpy(), ref32)
+    ell = formats.csr_to_ell_rowmajor(csr)
+    assert np.array_equal(ops.spmm_ell(ops.DeviceELL.from_host(ell), bview).cpu().numpy(), ref32)
+    pad = (-csr.num_cols) % 4
+    bsr = formats.csr_to_bsr(formats.CSR(300, k_rows + pad, csr.row_ptrs, csr.col_idxs, csr.data), 4)
+    bb = torch.zeros((k_rows + pad, ldb), dtype=torch.float32, device="cuda")[:, :n]
+    bb[:k_rows].copy_(dev(b))
+    refb = oracle.spmm_bsr(300, 4, 4, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data,
+                           np.vstack([b, np.zeros((pad, n), np.float32)]))
+    assert np.array_equal(ops.spmm_bsr(ops.DeviceBSR.from_host(bsr), bb, kernel=1).cpu().numpy(), refb)
+    # the MFMA kernels decline instead of truncating offsets
+    bsr16 = formats.csr_to_bsr(formats.CSR(304, k_rows + (-k_rows) % 16, np.concatenate([csr.row_ptrs, np.full(4, csr.row_ptrs[-1], np.uint32)]),
+                                           csr.col_idxs, csr.data), 16)
+    with pytest.raises(capi.MispmmError) as e:
+        ops.spmm_bsr(ops.DeviceBSR.from_host(bsr16), torch.zeros((bsr16.num_cols, ldb), device="cuda")[:, :n], kernel=2, acc="fast")
+    assert e.value.status == capi.ERR_UNSUPPORTED
