@@ -35,11 +35,13 @@ struct EllRows {
 };
 
 template <int G, int VEC, class Acc, bool SC1, class Rows>
-__global__ __launch_bounds__(256) void row_gather_kernel(uint32_t M, Rows rows, const uint32_t *__restrict__ colIdxs,
-                                                         const float *__restrict__ vals, const float *__restrict__ B,
-                                                         uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
-                                                         uint32_t c_bytes, uint32_t ldc, uint32_t rb_chunk, uint32_t log2p,
-                                                         uint32_t cols_per_part) {
+__global__ __launch_bounds__(256) void row_gather_kernel(
+    // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
+    // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
+    // with a kernarg fetch in front of the row-pointer fetch
+    uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
+    const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
+    const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc) {
     constexpr int GROUPS = 256 / G;
     constexpr int U = 16;  // every B read of a <= 16-entry row is in flight at once
     using vec_t = typename VecOf<VEC>::type;
@@ -152,12 +154,12 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows>), grid, dim3(256), 0, a.stream, a.M, rows, a.colIdxs,
-                           a.vals, a.B, b_bytes, a.N, a.ldb, a.C, static_cast<uint32_t>(c_bytes), a.ldc, rb_chunk, t.log2p,
-                           cols_per_part);
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows>), grid, dim3(256), 0, a.stream, a.M, rb_chunk, t.log2p,
+                           cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
+                           static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows>), grid, dim3(256), 0, a.stream, a.M, rows, a.colIdxs,
-                           a.vals, a.B, b_bytes, a.N, a.ldb, a.C, 0u, a.ldc, rb_chunk, t.log2p, cols_per_part);
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows>), grid, dim3(256), 0, a.stream, a.M, rb_chunk, t.log2p,
+                           cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
 }
 
 // needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check

@@ -173,71 +173,82 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
 }
 
 // --------------------------------------------------------------------------------- bsr_mfma_bf16
-// One WORKGROUP per (block row, 64-column super-tile); its 4 waves split the block row's block
-// pairs round-robin (pair p -> wave p % 4), each keeps a partial 16 x 64 fp32 tile, and the partials
-// are summed through LDS in fixed wave order (deterministic) before the store.  MFMA 16x16x32 bf16:
-// lane (c, g) holds A[i = c][k = 8g .. 8g+7] and B[k = 8g .. 8g+7][j = c].  k slots 0..15 are the 16
-// columns of the pair's first block, slots 16..31 those of its second block (zero when an odd block
-// is left over).  A lane reads, for each of its 8 k rows, the 4 consecutive bf16 of columns
-// 4c .. 4c+3 (8 bytes, one per accumulator tile) and regroups them per tile with v_perm_b32: the
-// transpose B needs, done in registers.  Same two-deep software pipeline as the fp32 kernel.
+// One WORKGROUP per (block row, super-tile of 16 * TPL output columns); its 4 waves split the block
+// row's block pairs round-robin (pair p -> wave p % 4), each keeps a partial 16 x (16 * TPL) fp32
+// tile, and the partials are summed through LDS in fixed wave order (deterministic) before the
+// store.  MFMA 16x16x32 bf16: lane (c, g) holds A[i = c][k = 8g .. 8g+7] and B[k = 8g .. 8g+7][j = c].
+// k slots 0..15 are the 16 columns of the pair's first block, slots 16..31 those of its second
+// block (zero when an odd block is left over).  A lane reads, for each of its 8 k rows, the TPL
+// consecutive bf16 of columns TPL*c .. TPL*c + TPL-1 (one per accumulator tile: 16 bytes at
+// TPL = 8, so one wave-instruction covers 128 columns of 4 B rows) and regroups them per tile with
+// v_perm_b32: the transpose B needs, done in registers.  Two-deep software pipeline as in the fp32
+// kernel.  TPL = 8 (N >= 128) halves the B-read instruction count of TPL = 4: the kernel is bound by
+// the texture-address path (33 100 blocks each pull a 16 x N panel), not by MFMA or HBM.
+template <int TPL>
 struct Bf16Frag {
     u32x4_t araw;
-    u32x2_t braw[8];
+    uint32_t braw[8][TPL / 2];
 };
 
-template <bool C_BF16>
+template <int TPL, bool C_BF16>
 __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
                                                      uint32_t b_bytes, uint32_t N, uint32_t ldb, void *__restrict__ Cv,
                                                      uint32_t ldc, uint32_t xcd_chunk) {
-    __shared__ f32x4_t partial[3][4][64];  // waves 1..3, 4 tiles, one vector per lane (12 KiB)
+    __shared__ f32x4_t partial[3][TPL][64];  // waves 1..3, TPL tiles, one vector per lane
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = xcd_block(blockIdx.x, xcd_chunk);
     if (item >= Mb * nST) return;  // workgroup-uniform, before any barrier
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
-    const uint32_t ncol = st * 64 + c * 4;
+    const uint32_t ncol = st * (16 * TPL) + c * TPL;  // first of this lane's TPL interleaved output columns
     const rsrc_t rsrc = make_rsrc(B, b_bytes);
     const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
     const uint32_t ldb2 = ldb * 2u;
     const uint32_t khalf = (g & 1) * 8u;  // first block column of this lane's 8 k slots
     const uint32_t second = g >> 1;       // lanes g = 2,3 take the second block of the pair
 
-    f32x4_t acc[4];
+    f32x4_t acc[TPL];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPL; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
     const uint32_t npairs = (be - bs + 1) / 2;
     if (wave < npairs) {
         const uint32_t last = be - 1;
         auto block_of = [&](uint32_t pair) { return bs + 2 * pair + second; };
-        auto load_frag = [&](uint32_t pair, uint32_t bcol, Bf16Frag &f) {
+        auto load_frag = [&](uint32_t pair, uint32_t bcol, Bf16Frag<TPL> &f) {
             const uint32_t b = block_of(pair);
             const bool have = b <= last;  // false for the missing half of an odd pair and past the row
             f.araw = *reinterpret_cast<const u32x4_t *>(blocks + static_cast<size_t>(min(b, last)) * 256u + c * 16u + khalf);
             if (!have) f.araw = u32x4_t{0u, 0u, 0u, 0u};
             // the block column differs between the two halves of the wave, so the whole row offset
-            // is per-lane (voffset); soffset stays 0
+            // is per-lane (voffset); soffset stays 0 (a non-uniform soffset costs a waterfall loop)
             const uint32_t voff = have ? lane_off + (bcol * 16u + khalf) * ldb2 : kDropLoad;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + e * ldb2, 0, 0);
-                f.braw[e] = __builtin_bit_cast(u32x2_t, r);
+                if constexpr (TPL == 8) {
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + e * ldb2, 0, 0);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) f.braw[e][w] = r[w];
+                } else {
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + e * ldb2, 0, 0);
+                    f.braw[e][0] = r[0];
+                    f.braw[e][1] = r[1];
+                }
             }
         };
         uint32_t col_next = blockColIdxs[min(block_of(wave + 4), last)];
-        Bf16Frag cur;
+        Bf16Frag<TPL> cur;
         load_frag(wave, blockColIdxs[min(block_of(wave), last)], cur);
         for (uint32_t pair = wave; pair < npairs; pair += 4) {
             const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 8), last)];
-            Bf16Frag nxt;
+            Bf16Frag<TPL> nxt;
             load_frag(pair + 4, col_next, nxt);
             const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, cur.araw);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TPL; ++t) {
                 // tile t takes bf16 element t of every k row: dword t>>1, half t&1
                 u32x4_t packed;
 #pragma unroll
@@ -255,14 +266,14 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
     // fixed-order reduction of the four partial tiles: wave 0 adds waves 1, 2, 3 in that order
     if (wave != 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) partial[wave - 1][t][lane] = acc[t];
+        for (int t = 0; t < TPL; ++t) partial[wave - 1][t][lane] = acc[t];
     }
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] += partial[w][t][lane];
+        for (int t = 0; t < TPL; ++t) acc[t] += partial[w][t][lane];
     }
     if (ncol < N) {
 #pragma unroll
@@ -270,13 +281,19 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
             const size_t crow = static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol;
             if constexpr (C_BF16) {
                 using bf2 = __bf16 __attribute__((ext_vector_type(2)));
-                u32x2_t o;
-                o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[0][r]), static_cast<__bf16>(acc[1][r])});
-                o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[2][r]), static_cast<__bf16>(acc[3][r])});
-                *reinterpret_cast<u32x2_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
+                uint32_t o[TPL / 2];
+#pragma unroll
+                for (int w = 0; w < TPL / 2; ++w)
+                    o[w] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[2 * w][r]), static_cast<__bf16>(acc[2 * w + 1][r])});
+                uint16_t *dst = static_cast<uint16_t *>(Cv) + crow;
+                if constexpr (TPL == 8) *reinterpret_cast<u32x4_t *>(dst) = u32x4_t{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<u32x2_t *>(dst) = u32x2_t{o[0], o[1]};
             } else {
-                const f32x4_t out{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-                *reinterpret_cast<f32x4_t *>(static_cast<float *>(Cv) + crow) = out;
+                float *dst = static_cast<float *>(Cv) + crow;
+#pragma unroll
+                for (int w = 0; w < TPL / 4; ++w)
+                    *reinterpret_cast<f32x4_t *>(dst + 4 * w) =
+                        f32x4_t{acc[4 * w][r], acc[4 * w + 1][r], acc[4 * w + 2][r], acc[4 * w + 3][r]};
             }
         }
     }
@@ -381,16 +398,22 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: leading dimension smaller than N");
     if (!mfma_shape_ok(K, N, ldb, ldc, B, C, blocks, 2) || (!c_bf16 && !aligned16(C)))
         return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: N/ldb/ldc must be multiples of 4 and operands vector-aligned");
-    const uint32_t nST = ceil_div(N, 64u);
+    // 8 tiles per lane (128-column super-tiles, 16-byte B reads) once N fills them and 16-byte vectors
+    // line up; else 4 tiles (64 columns, 8-byte reads)
+    const bool wide = N >= 128 && N % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && aligned16(B) && aligned16(C);
+    const uint32_t nST = ceil_div(N, wide ? 128u : 64u);
     const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, super-tile)
     dim3 grid(xg.grid);
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
-    if (c_bf16)
-        hipLaunchKernelGGL(bsr_mfma_bf16<true>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
-    else
-        hipLaunchKernelGGL(bsr_mfma_bf16<false>, grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs,
-                           blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
+#define MISPMM_BF16_LAUNCH(TPL, CB)                                                                                   \
+    hipLaunchKernelGGL((bsr_mfma_bf16<TPL, CB>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, \
+                       blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk)
+    if (wide) {
+        if (c_bf16) MISPMM_BF16_LAUNCH(8, true); else MISPMM_BF16_LAUNCH(8, false);
+    } else {
+        if (c_bf16) MISPMM_BF16_LAUNCH(4, true); else MISPMM_BF16_LAUNCH(4, false);
+    }
+#undef MISPMM_BF16_LAUNCH
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }
