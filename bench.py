@@ -69,7 +69,7 @@ def cpu_baseline(csr, b, budget_s, gpu_result, acc):
     if parity == "MISMATCH":
         raise SystemExit("bench: GPU result does not match the oracle -- refusing to report a number")
     times, t_end = [], time.perf_counter() + budget_s
-    while time.perf_counter() < t_end and len(times) < 400:
+    while time.perf_counter() < t_end and len(times) < 5000:
         t0 = time.perf_counter()
         orc.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
         times.append(time.perf_counter() - t0)
@@ -77,7 +77,7 @@ def cpu_baseline(csr, b, budget_s, gpu_result, acc):
     return {"value": round(2.0 * csr.nnz * b.shape[1] / best / 1e9, 3), "unit": "GFLOP/s", "cores": 1,
             "kind": "port", "ms_per_step": round(best * 1e3, 4), "gpu_parity": parity,
             "sample": f"the full workload ({csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x K={b.shape[1]}), "
-                      f"best of {len(times)} runs in <= {budget_s:.0f} s, oracle/spmm_oracle.c -O2, "
+                      f"best of {len(times)} runs in {budget_s:.0f} s, oracle/spmm_oracle.c -O2, "
                       f"host has {os.cpu_count()} logical cores"}
 
 

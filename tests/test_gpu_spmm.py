@@ -375,6 +375,18 @@ def test_wide_address_fallbacks_for_b_beyond_2gib(oracle):
     refb = oracle.spmm_bsr(300, 4, 4, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data,
                            np.vstack([b, np.zeros((pad, n), np.float32)]))
     assert np.array_equal(ops.spmm_bsr(ops.DeviceBSR.from_host(bsr), bb, kernel=1).cpu().numpy(), refb)
+    # a C whose rows are 8 MiB apart (2.5 GiB span): write-through buffer stores no longer fit, plain stores take over
+    del big, bb
+    torch.cuda.empty_cache()
+    small = random_csr(300, 500, rng.integers(0, 20, size=300), seed=23)
+    bs = synth.dense_b(500, 64)
+    huge_c = torch.full((300, 2 ** 21), -1.0, dtype=torch.float32, device="cuda")
+    cview = huge_c[:, :64]
+    ops.spmm_csr(ops.DeviceCSR.from_host(small), dev(bs), out=cview)
+    assert np.array_equal(cview.cpu().numpy(), oracle.spmm_csr(small.row_ptrs, small.col_idxs, small.data, bs))
+    assert float(huge_c[:, 64:128].max()) == -1.0
+    del huge_c
+    torch.cuda.empty_cache()
     # the MFMA kernels decline instead of truncating offsets
     bsr16 = formats.csr_to_bsr(formats.CSR(304, k_rows + (-k_rows) % 16, np.concatenate([csr.row_ptrs, np.full(4, csr.row_ptrs[-1], np.uint32)]),
                                            csr.col_idxs, csr.data), 16)
