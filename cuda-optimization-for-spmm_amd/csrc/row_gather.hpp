@@ -167,23 +167,37 @@ struct XcdTiling {
 };
 
 inline XcdTiling xcd_tiling(uint32_t N, int vec) {
+    // environment overrides are read once per process
+    struct Env {
+        int log2p = -1;
+        uint32_t q = 0;
+        int sc1 = -1;
+        Env() {
+            if (const char *e = getenv("MISPMM_CSR_TILING")) {
+                unsigned pp = 8, qq = 1;
+                if (sscanf(e, "%u,%u", &pp, &qq) == 2 && pp * qq == 8 && (pp == 1 || pp == 2 || pp == 4 || pp == 8)) {
+                    log2p = pp == 1 ? 0 : pp == 2 ? 1 : pp == 4 ? 2 : 3;
+                    q = qq;
+                }
+            }
+            if (const char *e = getenv("MISPMM_STORE_SC1")) sc1 = e[0] != '0';
+        }
+    };
+    static const Env env;
     // default: 4 row parts x 2 column parts once a half-width part still fills 32-lane row groups
     // (measured on n4c6-b13 x 128: 4.26 us vs 4.48 us for 8 x 1); otherwise 8 x 1
     XcdTiling t{3u, 1u, true};
     if (N >= 128 && N % (2u * 32u * vec) == 0) t = XcdTiling{2u, 2u, true};
-    if (const char *e = getenv("MISPMM_CSR_TILING")) {
-        unsigned pp = 8, qq = 1;
-        if (sscanf(e, "%u,%u", &pp, &qq) == 2 && pp * qq == 8 && (pp == 1 || pp == 2 || pp == 4 || pp == 8)) {
-            t.log2p = pp == 1 ? 0u : pp == 2 ? 1u : pp == 4 ? 2u : 3u;
-            t.q = qq;
-        }
+    if (env.log2p >= 0) {
+        t.log2p = static_cast<uint32_t>(env.log2p);
+        t.q = env.q;
     }
     // a column part must hold at least one 8-lane group of whole vectors
     while (t.q > 1 && (N % t.q != 0 || (N / t.q) % (8u * vec) != 0)) {
         t.q >>= 1;
         ++t.log2p;
     }
-    if (const char *e = getenv("MISPMM_STORE_SC1")) t.sc1 = e[0] != '0';
+    if (env.sc1 >= 0) t.sc1 = env.sc1 != 0;
     return t;
 }
 

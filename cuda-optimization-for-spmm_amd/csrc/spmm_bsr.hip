@@ -299,6 +299,129 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
     }
 }
 
+// ----------------------------------------------------------------------------- bsr_mfma_bf16_b32
+// 32 x 32 blocks: a block's 32 columns are exactly the K = 32 of one v_mfma_f32_16x16x32_bf16, so no
+// pairing; its 32 rows are two 16-row halves that share the B fragment (one B fetch, two MFMAs per
+// tile).  Work split, column interleave, pipeline and LDS reduction as in the 16 x 16 kernel.
+template <int TPL>
+struct Bf16Frag32 {
+    u32x4_t araw[2];
+    uint32_t braw[8][TPL / 2];
+};
+
+template <int TPL, bool C_BF16>
+__global__ __launch_bounds__(256) void bsr_mfma_bf16_b32(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
+                                                         const uint32_t *__restrict__ blockColIdxs,
+                                                         const uint16_t *__restrict__ blocks,
+                                                         const uint16_t *__restrict__ B, uint32_t b_bytes, uint32_t N,
+                                                         uint32_t ldb, void *__restrict__ Cv, uint32_t ldc,
+                                                         uint32_t xcd_chunk) {
+    __shared__ f32x4_t partial[3][2 * TPL][64];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk);
+    if (item >= Mb * nST) return;  // workgroup-uniform, before any barrier
+    const uint32_t R = item / nST, st = item - R * nST;
+    const uint32_t c = lane & 15, g = lane >> 4;
+    const uint32_t ncol = st * (16 * TPL) + c * TPL;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
+    const uint32_t ldb2 = ldb * 2u;
+
+    f32x4_t acc[2][TPL];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < TPL; ++t) acc[h][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
+    if (bs + wave < be) {
+        const uint32_t last = be - 1;
+        auto load_frag = [&](uint32_t b, uint32_t bcol, Bf16Frag32<TPL> &f) {
+            const bool have = b <= last;
+            const uint16_t *ablk = blocks + static_cast<size_t>(min(b, last)) * 1024u + c * 32u + g * 8u;
+            f.araw[0] = *reinterpret_cast<const u32x4_t *>(ablk);
+            f.araw[1] = *reinterpret_cast<const u32x4_t *>(ablk + 16 * 32);
+            const uint32_t voff = have ? lane_off + (bcol * 32u + g * 8u) * ldb2 : kDropLoad;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (TPL == 8) {
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + e * ldb2, 0, 0);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) f.braw[e][w] = r[w];
+                } else {
+                    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + e * ldb2, 0, 0);
+                    f.braw[e][0] = r[0];
+                    f.braw[e][1] = r[1];
+                }
+            }
+        };
+        uint32_t col_next = blockColIdxs[min(bs + wave + 4, last)];
+        Bf16Frag32<TPL> cur;
+        load_frag(bs + wave, blockColIdxs[bs + wave], cur);
+        for (uint32_t b = bs + wave; b < be; b += 4) {
+            const uint32_t col_next2 = blockColIdxs[min(b + 8, last)];
+            Bf16Frag32<TPL> nxt;
+            load_frag(b + 4, col_next, nxt);  // dropped B reads past the row; the A it re-reads is never used
+            const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, cur.araw[0]);
+            const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, cur.araw[1]);
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                u32x4_t packed;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t lo = cur.braw[2 * p][t >> 1], hi = cur.braw[2 * p + 1][t >> 1];
+                    packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u) : __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+                }
+                const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, packed);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfrag, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfrag, acc[1][t], 0, 0, 0);
+            }
+            cur = nxt;
+            col_next = col_next2;
+        }
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) partial[wave - 1][h * TPL + t][lane] = acc[h][t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) acc[h][t] += partial[w][h * TPL + t][lane];
+    if (ncol < N) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t crow = static_cast<size_t>(R * 32 + h * 16 + g * 4 + r) * ldc + ncol;
+                if constexpr (C_BF16) {
+                    using bf2 = __bf16 __attribute__((ext_vector_type(2)));
+                    uint32_t o[TPL / 2];
+#pragma unroll
+                    for (int w = 0; w < TPL / 2; ++w)
+                        o[w] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[h][2 * w][r]),
+                                                                static_cast<__bf16>(acc[h][2 * w + 1][r])});
+                    uint16_t *dst = static_cast<uint16_t *>(Cv) + crow;
+                    if constexpr (TPL == 8) *reinterpret_cast<u32x4_t *>(dst) = u32x4_t{o[0], o[1], o[2], o[3]};
+                    else *reinterpret_cast<u32x2_t *>(dst) = u32x2_t{o[0], o[1]};
+                } else {
+                    float *dst = static_cast<float *>(Cv) + crow;
+#pragma unroll
+                    for (int w = 0; w < TPL / 4; ++w)
+                        *reinterpret_cast<f32x4_t *>(dst + 4 * w) =
+                            f32x4_t{acc[h][4 * w][r], acc[h][4 * w + 1][r], acc[h][4 * w + 2][r], acc[h][4 * w + 3][r]};
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- dispatch
 struct BsrArgs {
     hipStream_t stream;
@@ -391,7 +514,8 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
                                uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,
                                const uint16_t *blocks, const uint16_t *B, uint32_t N, uint32_t ldb, void *C,
                                uint32_t ldc, int c_bf16) {
-    if (bR != 16 || bC != 16) return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: only 16x16 blocks (got %ux%u)", bR, bC);
+    if (!((bR == 16 && bC == 16) || (bR == 32 && bC == 32)))
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsr_bf16: only 16x16 or 32x32 blocks (got %ux%u)", bR, bC);
     if (numBlockRows == 0 || N == 0) return MISPMM_OK;
     if (!blockRowPtrs || !B || !C) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: null pointer");
     if (numBlocks != 0 && (!blockColIdxs || !blocks)) return fail(MISPMM_ERR_INVALID_ARG, "bsr_bf16: null block arrays");
@@ -405,14 +529,20 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, super-tile)
     dim3 grid(xg.grid);
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
-#define MISPMM_BF16_LAUNCH(TPL, CB)                                                                                   \
-    hipLaunchKernelGGL((bsr_mfma_bf16<TPL, CB>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, \
+#define MISPMM_BF16_LAUNCH(KERNEL, TPL, CB)                                                                     \
+    hipLaunchKernelGGL((KERNEL<TPL, CB>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, \
                        blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk)
-    if (wide) {
-        if (c_bf16) MISPMM_BF16_LAUNCH(8, true); else MISPMM_BF16_LAUNCH(8, false);
-    } else {
-        if (c_bf16) MISPMM_BF16_LAUNCH(4, true); else MISPMM_BF16_LAUNCH(4, false);
-    }
+#define MISPMM_BF16_PICK(KERNEL)                                                                 \
+    do {                                                                                         \
+        if (wide) {                                                                              \
+            if (c_bf16) MISPMM_BF16_LAUNCH(KERNEL, 8, true); else MISPMM_BF16_LAUNCH(KERNEL, 8, false); \
+        } else {                                                                                 \
+            if (c_bf16) MISPMM_BF16_LAUNCH(KERNEL, 4, true); else MISPMM_BF16_LAUNCH(KERNEL, 4, false); \
+        }                                                                                        \
+    } while (0)
+    if (bR == 16) MISPMM_BF16_PICK(bsr_mfma_bf16);
+    else MISPMM_BF16_PICK(bsr_mfma_bf16_b32);
+#undef MISPMM_BF16_PICK
 #undef MISPMM_BF16_LAUNCH
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;

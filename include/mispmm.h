@@ -162,7 +162,7 @@ int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, ui
 #define MISPMM_BSR_NUM_KERNELS 2
 
 /* bf16 blocks and B (raw bf16 bit patterns), fp32 accumulate on
- * v_mfma_f32_16x16x32_bf16; bR = bC = 16 or 32.  C is fp32 (c_bf16 = 0) or bf16.
+ * v_mfma_f32_16x16x32_bf16; bR = bC = 16 (two blocks per instruction) or 32.  C is fp32 (c_bf16 = 0) or bf16.
  * New capability (BASELINE.json config 4); the reference has no bf16 path. */
 int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t bR, uint32_t bC,
                     uint32_t numBlocks, const uint32_t *blockRowPtrs, const uint32_t *blockColIdxs,

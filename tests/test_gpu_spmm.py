@@ -303,12 +303,13 @@ def test_bsr_mfma_f32_equals_fast_valu_bitwise(oracle, name, n):
     assert np.array_equal(ops.spmm_bsr(a, dev(b), kernel=0, acc="fast").cpu().numpy(), mfma)   # auto picks MFMA
 
 
-@pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (4, False)])
-def test_bsr_bf16_mfma(oracle, n, out_bf16):
-    """BASELINE config 4 (large_20000 BSR-16 x K=128 bf16).  Oracle = the reference's BSR CPU
-    semantics on bf16-rounded A and B (the reference itself has no bf16)."""
+@pytest.mark.parametrize("block", [16, 32])
+@pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (4, False), (256, True)])
+def test_bsr_bf16_mfma(oracle, n, out_bf16, block):
+    """BASELINE config 4 (large_20000 BSR-16 x K=128 bf16), and 32 x 32 blocks.  Oracle = the reference's
+    BSR CPU semantics on bf16-rounded A and B (the reference itself has no bf16)."""
     csr = datasets.load_csr("ACTIVSg10K")
-    bsr = formats.csr_to_bsr(csr, 16)
+    bsr = formats.csr_to_bsr(csr, block)
     a = ops.DeviceBSR.from_host(bsr)
     b = synth.dense_b(csr.num_cols, n)
     a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
@@ -316,7 +317,7 @@ def test_bsr_bf16_mfma(oracle, n, out_bf16):
     blocks_bits = ops.f32_to_bf16(a.data)
     b_bits = ops.f32_to_bf16(dev(b))
     assert np.array_equal(ops.bf16_to_f32(blocks_bits).cpu().numpy().reshape(a16.shape), a16), "device RNE == host RNE"
-    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    ref = oracle.spmm_bsr(bsr.num_rows, block, block, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
     c = ops.spmm_bsr_bf16(a, blocks_bits, b_bits, out_bf16=out_bf16)
     got = (ops.bf16_to_f32(c) if out_bf16 else c).cpu().numpy()
     scale = abs_scale(formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs,
