@@ -2,6 +2,8 @@
 //
 // Replaces /root/reference/src/spmm/bsr/spmm_bsr_k1.cu (one thread per block element, an
 // atomicAdd per output element and term).  Three kernels, none with atomics:
+//   bsr_rowblock  square blocks of 4 / 8 / 16 / 32 (kernel 1's fast path): a wave owns a block row,
+//             keeps its BD x VEC partial sums in registers, fetches each B row once per block row.
 //   bsr_valu  any block shape.  A C row is a CSR row whose terms are (block, column-in-block)
 //             pairs: G lanes own one C row, the coefficients of 16 terms are fetched by one
 //             coalesced load and broadcast by shuffle, B rows come as dropped-or-live buffer
@@ -98,6 +100,93 @@ __global__ __launch_bounds__(256) void bsr_valu(uint32_t M, uint32_t bR, uint32_
 #pragma unroll
         for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
         store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------- bsr_rowblock
+// Square blocks of 4, 8, 16 or 32: one wave owns RS = min(BD, 8) rows of a block row for 64 * VEC
+// columns and keeps its RS x VEC partial sums per lane in registers, so every B row of a block is
+// fetched once per RS rows instead of once per C row (bsr_valu moves RS x the bytes through L1); the
+// BD / RS row slices of a block row run as neighbouring waves (enough waves to fill the chip: the
+// kernel is bound by the unfused multiply + add stream, 2 x 8.5 M terms x N lane-ops).
+// Each block is staged in the wave's own LDS slice by one coalesced load per 256 values and its
+// coefficients come back as broadcast ds_reads; the terms of a C element are still added block by
+// block in storage order and by ascending column inside a block, with the accumulate policy's
+// rounding -- REFERENCE mode stays bit-identical to spmmBSRCpu.  Wave-private LDS: no barrier.
+template <int BD, int RS, int VEC, class Acc>
+__global__ __launch_bounds__(256) void bsr_rowblock(uint32_t Mb, uint32_t nCT, const uint32_t *__restrict__ blockRowPtrs,
+                                                    const uint32_t *__restrict__ blockColIdxs,
+                                                    const float *__restrict__ blocks, const float *__restrict__ B,
+                                                    uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
+                                                    uint32_t ldc, uint32_t xcd_chunk) {
+    using vec_t = typename VecOf<VEC>::type;
+    constexpr int PARTS = BD / RS;            // row slices of a block row, one wave each
+    constexpr int SUB = RS * BD;              // block values a wave needs: its RS rows
+    constexpr int PER_LANE = (SUB + 63) / 64;  // values each lane stages
+    __shared__ float stage[4][2][SUB < 64 ? 64 : SUB];  // [wave][double buffer][RS x BD values]
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk) * 4 + wave;
+    if (item >= Mb * nCT * PARTS) return;  // wave-uniform; no workgroup barrier anywhere in this kernel
+    const uint32_t part = item % PARTS, rest = item / PARTS;  // row slices of one block row sit on one CU: shared B rows hit L1
+    const uint32_t R = rest / nCT, ct = rest - R * nCT;
+    const uint32_t col0 = ct * (64 * VEC) + lane * VEC;
+    const bool col_ok = col0 < N;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;
+    const uint32_t ldb4 = ldb * 4u;
+
+    typename Acc::T acc[RS][VEC];
+#pragma unroll
+    for (int i = 0; i < RS; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[i][v] = 0;
+
+    const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
+    float areg[PER_LANE];
+    auto load_block = [&](uint32_t b) {  // coalesced: lane l takes values l, l + 64, ... of the wave's RS rows
+        const float *sub = blocks + static_cast<size_t>(b) * (BD * BD) + part * SUB;
+#pragma unroll
+        for (int p = 0; p < PER_LANE; ++p) {
+            const uint32_t idx = p * 64 + lane;
+            areg[p] = idx < SUB ? sub[idx] : 0.f;
+        }
+    };
+    if (bs < be) load_block(bs);
+    for (uint32_t b = bs; b < be; ++b) {
+        float *slot = stage[wave][(b - bs) & 1];
+#pragma unroll
+        for (int p = 0; p < PER_LANE; ++p) {
+            const uint32_t idx = p * 64 + lane;
+            if (idx < SUB) slot[idx] = areg[p];
+        }
+        const uint32_t brow0 = blockColIdxs[b] * BD;
+        if (b + 1 < be) load_block(b + 1);  // next block's values fly while this one is multiplied
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ds_writes of this wave before its ds_reads
+#pragma unroll 1
+        for (int j0 = 0; j0 < BD; j0 += 4) {
+            vec_t bv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bv[jj] = buffer_load_vec<VEC>(rsrc, lane_off, (brow0 + j0 + jj) * ldb4);
+#pragma unroll
+            for (int i = 0; i < RS; ++i) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(slot + i * BD + j0);  // broadcast read
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[i][v], a4[jj], vec_get<VEC>(bv[jj], v));
+                }
+            }
+        }
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            vec_t out;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[i][v]));
+            store_vec<VEC>(C + static_cast<size_t>(R * BD + part * RS + i) * ldc + col0, out);
+        }
     }
 }
 
@@ -456,8 +545,35 @@ static void launch_valu_g(const BsrArgs &a, int g) {
     }
 }
 
+template <int BD, int VEC, class Acc>
+static void launch_rowblock(const BsrArgs &a) {
+    constexpr int RS = BD < 8 ? BD : 8;
+    const uint32_t nCT = ceil_div(a.N, 64u * VEC);
+    const XcdGrid xg = xcd_grid(ceil_div(a.Mb * nCT * (BD / RS), 4u));
+    hipLaunchKernelGGL((bsr_rowblock<BD, RS, VEC, Acc>), dim3(xg.grid), dim3(256), 0, a.stream, a.Mb, nCT, a.ptrs, a.idxs,
+                       a.blocks, a.B, static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u), a.N, a.ldb, a.C, a.ldc,
+                       xg.chunk);
+}
+
+// true when the block-row kernel took the launch
+template <class Acc>
+static bool try_rowblock(const BsrArgs &a, int vec) {
+    if (a.bR != a.bC || static_cast<uint64_t>(a.K) * a.ldb * 4u > 0x7FFFFFFFull) return false;
+    if (vec == 4 && a.N <= 128) vec = 2;  // keep all 64 lanes busy at N <= 128
+#define MISPMM_RB_CASE(BD, VV)                  \
+    if (a.bR == BD && vec == VV) {              \
+        launch_rowblock<BD, VV, Acc>(a);        \
+        return true;                            \
+    }
+    MISPMM_RB_CASE(4, 1) MISPMM_RB_CASE(4, 2) MISPMM_RB_CASE(4, 4) MISPMM_RB_CASE(8, 1) MISPMM_RB_CASE(8, 2) MISPMM_RB_CASE(8, 4)
+    MISPMM_RB_CASE(16, 1) MISPMM_RB_CASE(16, 2) MISPMM_RB_CASE(16, 4) MISPMM_RB_CASE(32, 1) MISPMM_RB_CASE(32, 2) MISPMM_RB_CASE(32, 4)
+#undef MISPMM_RB_CASE
+    return false;
+}
+
 template <class Acc>
 static void launch_valu_v(const BsrArgs &a, int vec) {
+    if (try_rowblock<Acc>(a, vec)) return;
     const int g = pick_group(a.N, vec);
     if (vec == 4) launch_valu_g<4, Acc>(a, g);
     else if (vec == 2) launch_valu_g<2, Acc>(a, g);
