@@ -35,15 +35,15 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows>
-__global__ __launch_bounds__(256) void row_gather_kernel(
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256>
+__global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
     uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
     const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc) {
-    constexpr int GROUPS = 256 / G;
+    constexpr int GROUPS = BLOCK / G;
     constexpr int U = G < 16 ? G : 16;  // B reads in flight per lane; a row of <= U entries is ONE batch
     using vec_t = typename VecOf<VEC>::type;
     const uint32_t lane = threadIdx.x % G;
@@ -201,21 +201,32 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     return t;
 }
 
-template <int G, int VEC, class Acc, class Rows>
-void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
+template <int G, int VEC, class Acc, class Rows, int BLOCK>
+void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
     const uint32_t cols_per_part = a.N / t.q;
-    const uint32_t rb = ceil_div(a.M, 256 / G);
+    const uint32_t rb = ceil_div(a.M, BLOCK / G);
     const uint32_t rb_chunk = ceil_div(rb, 1u << t.log2p);
     dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows>), grid, dim3(256), 0, a.stream, a.M, rb_chunk, t.log2p,
-                           cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
                            static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows>), grid, dim3(256), 0, a.stream, a.M, rb_chunk, t.log2p,
-                           cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
+}
+
+template <int G, int VEC, class Acc, class Rows>
+void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
+    // 128-thread workgroups: with 256 threads a CU holds 3.08 workgroups on the headline, so some CUs
+    // carry 4 and finish late; halving the granule measured 4.49 -> 4.24 us (REFERENCE) and 4.37 -> 4.02 us
+    // (FAST); 64 threads gave 4.45 / 4.10.  MISPMM_BLOCK=64|128|256 overrides (measurement aid).
+    static const int block = [] { const char *e = getenv("MISPMM_BLOCK"); return e ? atoi(e) : 128; }();
+    if (block == 64) launch_row_gather_b<G, VEC, Acc, Rows, 64>(a, rows, t);
+    else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256>(a, rows, t);
+    else launch_row_gather_b<G, VEC, Acc, Rows, 128>(a, rows, t);
 }
 
 // needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check
