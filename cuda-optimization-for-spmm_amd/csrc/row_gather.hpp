@@ -184,10 +184,16 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
         }
     };
     static const Env env;
-    // default: 4 row parts x 2 column parts once a half-width part still fills 32-lane row groups
-    // (measured on n4c6-b13 x 128: 4.26 us vs 4.48 us for 8 x 1); otherwise 8 x 1
+    // default: column parts of 64 columns (16 lanes x 4) -- Q = N / 64 up to 8, P = 8 / Q row parts.
+    // Measured on n4c6-b13: N = 128 -> 4 x 2 (4.25 us vs 4.41 us for 8 x 1); N = 512 -> 1 x 8 (15.5 us vs
+    // 16.0 / 17.0 / 18.8 us for 2 x 4 / 4 x 2 / 8 x 1).  Narrow or odd N keeps 8 x 1.
     XcdTiling t{3u, 1u, true};
-    if (N >= 128 && N % (2u * 32u * vec) == 0) t = XcdTiling{2u, 2u, true};
+    if (vec == 4 && N >= 128 && N % 64 == 0) {
+        uint32_t q = 2;
+        while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 64) == 0) q *= 2;
+        t.q = q;
+        t.log2p = q == 2 ? 2u : q == 4 ? 1u : 0u;
+    }
     if (env.log2p >= 0) {
         t.log2p = static_cast<uint32_t>(env.log2p);
         t.q = env.q;
