@@ -35,7 +35,7 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256>
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16>
 __global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
     const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc) {
     constexpr int GROUPS = BLOCK / G;
-    constexpr int U = G < 16 ? G : 16;  // B reads in flight per lane; a row of <= U entries is ONE batch
+    constexpr int U = G < UMAX ? G : UMAX;  // B reads in flight per lane; a row of <= U entries is ONE batch
     using vec_t = typename VecOf<VEC>::type;
     const uint32_t lane = threadIdx.x % G;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -102,8 +102,8 @@ __global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     using FullBatch = std::integral_constant<int, U>;
 
     if (!__any(row_len > static_cast<uint32_t>(U))) {
-        // Every row of this wave fits one batch (the BASELINE matrices: 14 entries per row): one
-        // (col, val) fetch, U B reads in flight, one pass of multiply-adds.  Wave-uniform branch.
+        // Every row of this wave fits one batch: one (col, val) fetch, U B reads in flight, one pass of
+        // multiply-adds.  Wave-uniform branch.
         if (row_len != 0) {
             uint32_t my_off;
             float my_val;
@@ -207,7 +207,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     return t;
 }
 
-template <int G, int VEC, class Acc, class Rows, int BLOCK>
+template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16>
 void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
     const uint32_t cols_per_part = a.N / t.q;
     const uint32_t rb = ceil_div(a.M, BLOCK / G);
@@ -216,11 +216,11 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
                            static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
 }
 
@@ -230,9 +230,14 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     // carry 4 and finish late; halving the granule measured 4.49 -> 4.24 us (REFERENCE) and 4.37 -> 4.02 us
     // (FAST); 64 threads gave 4.45 / 4.10.  MISPMM_BLOCK=64|128|256 overrides (measurement aid).
     static const int block = [] { const char *e = getenv("MISPMM_BLOCK"); return e ? atoi(e) : 128; }();
-    if (block == 64) launch_row_gather_b<G, VEC, Acc, Rows, 64>(a, rows, t);
-    else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256>(a, rows, t);
-    else launch_row_gather_b<G, VEC, Acc, Rows, 128>(a, rows, t);
+    // 8 reads in flight per lane, not 16: 74 instead of 120 VGPRs lets 6 waves per SIMD stay resident, which
+    // beats finishing a 14-entry row in one batch (same box, headline: 4.25 -> 4.21 us REFERENCE, 4.43 -> 3.78 us
+    // FAST; K = 256: 8.15 -> 7.59 us; K = 512: 15.5 -> 14.7 us).  MISPMM_UMAX=16 restores the deep batch.
+    static const int umax = [] { const char *e = getenv("MISPMM_UMAX"); return e ? atoi(e) : 8; }();
+    if (block == 64) launch_row_gather_b<G, VEC, Acc, Rows, 64, 8>(a, rows, t);
+    else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256, 8>(a, rows, t);
+    else if (umax == 16) launch_row_gather_b<G, VEC, Acc, Rows, 128, 16>(a, rows, t);
+    else launch_row_gather_b<G, VEC, Acc, Rows, 128, 8>(a, rows, t);
 }
 
 // needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check

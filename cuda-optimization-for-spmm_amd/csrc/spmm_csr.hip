@@ -12,6 +12,9 @@
 //   k3  one wave per row: one coalesced vector load per 64 (col, val) pairs, v_readlane moves each
 //       pair to SGPRs, so the B row base is an SGPR pair and each B read a saddr-form global_load
 //   k4  k3 with two rows interleaved per wave (half the waves, twice the loads in flight)
+//   k5  (default) k1's row groups in 128-thread workgroups laid over the XCDs as a (row part x column
+//       part) grid, one 16-read batch per short row, write-through C stores: row_gather.hpp, shared
+//       with ELL and COO
 // Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
 #include "row_gather.hpp"
@@ -24,7 +27,7 @@ namespace mispmm {
 // only the arithmetic is predicated.
 
 // ---------------------------------------------------------------------------------- wide fallback
-// 64-bit addressing, for a B that spans 4 GiB or more (buffer offsets are 32-bit).  Same work
+// 64-bit addressing, for a B that spans 2 GiB or more (buffer offsets are 32-bit, bit 31 = drop).  Same work
 // split as k1; the unused slots of a batch re-read the row's last entry instead of being dropped.
 template <int G, int VEC, class Acc>
 __global__ __launch_bounds__(256) void csr_wide(uint32_t M, const uint32_t *__restrict__ rowPtrs,

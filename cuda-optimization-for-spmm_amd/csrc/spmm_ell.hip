@@ -13,7 +13,7 @@
 
 namespace mispmm {
 
-// 64-bit-address fallback for a B of 4 GiB or more: padding / tail slots are skipped by predicate.
+// 64-bit-address fallback for a B of 2 GiB or more: padding / tail slots are skipped by predicate.
 template <int G, int VEC, class Acc>
 __global__ __launch_bounds__(256) void ell_wide(uint32_t M, uint32_t width, const uint32_t *__restrict__ colIdxs,
                                                 const float *__restrict__ vals, const float *__restrict__ B, uint32_t N,
