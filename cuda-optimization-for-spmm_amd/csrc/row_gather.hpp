@@ -188,7 +188,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     // Measured on n4c6-b13: N = 128 -> 4 x 2 (4.25 us vs 4.41 us for 8 x 1); N = 512 -> 1 x 8 (15.5 us vs
     // 16.0 / 17.0 / 18.8 us for 2 x 4 / 4 x 2 / 8 x 1).  Narrow or odd N keeps 8 x 1.
     XcdTiling t{3u, 1u, true};
-    if (vec == 4 && N >= 128 && N % 64 == 0) {
+    if (vec >= 2 && N >= 128 && N % 64 == 0) {
         uint32_t q = 2;
         while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 64) == 0) q *= 2;
         t.q = q;

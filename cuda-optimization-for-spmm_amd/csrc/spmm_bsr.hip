@@ -21,6 +21,8 @@
 // 16-byte (fp32) / 8-byte (bf16) vectors.
 // Roofline: HBM for bf16 (algorithmic bytes nb*bR*bC*e + nb*4 + (Mb+1)*4 + K*N*e + M*N*o);
 // fp32 MFMA runs at the fp32 vector rate and is MFMA-bound on low-fill blocks.
+#include <cstdlib>
+
 #include "spmm_common.hpp"
 
 namespace mispmm {
@@ -270,8 +272,7 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
 // block (zero when an odd block is left over).  A lane reads, for each of its 8 k rows, the TPL
 // consecutive bf16 of columns TPL*c .. TPL*c + TPL-1 (one per accumulator tile: 16 bytes at
 // TPL = 8, so one wave-instruction covers 128 columns of 4 B rows) and regroups them per tile with
-// v_perm_b32: the transpose B needs, done in registers.  Two-deep software pipeline as in the fp32
-// kernel.  TPL = 8 (N >= 128) halves the B-read instruction count of TPL = 4: the kernel is bound by
+// v_perm_b32: the transpose B needs, done in registers.  Optional two-deep software pipeline (PIPE).  TPL = 8 (N >= 128) halves the B-read instruction count of TPL = 4: the kernel is bound by
 // the texture-address path (33 100 blocks each pull a 16 x N panel), not by MFMA or HBM.
 template <int TPL>
 struct Bf16Frag {
@@ -279,7 +280,7 @@ struct Bf16Frag {
     uint32_t braw[8][TPL / 2];
 };
 
-template <int TPL, bool C_BF16>
+template <int TPL, bool C_BF16, bool PIPE = true>
 __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
@@ -328,28 +329,43 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
                 }
             }
         };
-        uint32_t col_next = blockColIdxs[min(block_of(wave + 4), last)];
-        Bf16Frag<TPL> cur;
-        load_frag(wave, blockColIdxs[min(block_of(wave), last)], cur);
-        for (uint32_t pair = wave; pair < npairs; pair += 4) {
-            const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 8), last)];
-            Bf16Frag<TPL> nxt;
-            load_frag(pair + 4, col_next, nxt);
-            const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, cur.araw);
+        auto multiply = [&](const Bf16Frag<TPL> &f) {
+            const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, f.araw);
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
                 // tile t takes bf16 element t of every k row: dword t>>1, half t&1
                 u32x4_t packed;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const uint32_t lo = cur.braw[2 * p][t >> 1], hi = cur.braw[2 * p + 1][t >> 1];
+                    const uint32_t lo = f.braw[2 * p][t >> 1], hi = f.braw[2 * p + 1][t >> 1];
                     packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u)   // {hi.h1, lo.h1}
                                         : __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, packed), acc[t], 0, 0, 0);
             }
-            cur = nxt;
-            col_next = col_next2;
+        };
+        if constexpr (PIPE) {
+            uint32_t col_next = blockColIdxs[min(block_of(wave + 4), last)];
+            Bf16Frag<TPL> cur;
+            load_frag(wave, blockColIdxs[min(block_of(wave), last)], cur);
+            for (uint32_t pair = wave; pair < npairs; pair += 4) {
+                const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 8), last)];
+                Bf16Frag<TPL> nxt;
+                load_frag(pair + 4, col_next, nxt);
+                multiply(cur);
+                cur = nxt;
+                col_next = col_next2;
+            }
+        } else {
+            // no register double buffer: half the fragment registers, more resident waves hide the latency
+            uint32_t col_cur = blockColIdxs[min(block_of(wave), last)];
+            for (uint32_t pair = wave; pair < npairs; pair += 4) {
+                const uint32_t col_next = blockColIdxs[min(block_of(pair + 4), last)];
+                Bf16Frag<TPL> cur;
+                load_frag(pair, col_cur, cur);
+                multiply(cur);
+                col_cur = col_next;
+            }
         }
     }
     // fixed-order reduction of the four partial tiles: wave 0 adds waves 1, 2, 3 in that order
@@ -648,6 +664,10 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
 #define MISPMM_BF16_LAUNCH(KERNEL, TPL, CB)                                                                     \
     hipLaunchKernelGGL((KERNEL<TPL, CB>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, \
                        blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk)
+    // the 128-column kernel runs WITHOUT the register double buffer by default: 72 instead of 104 VGPRs, and the
+    // extra resident waves hide the fetch latency better than the prefetch did (13.3 -> 12.2 us on config 4);
+    // MISPMM_BSR_PIPE=1 restores the two-deep software pipeline (measurement aid)
+    static const bool bsr_pipe = [] { const char *e = getenv("MISPMM_BSR_PIPE"); return e && e[0] == '1'; }();
 #define MISPMM_BF16_PICK(KERNEL)                                                                 \
     do {                                                                                         \
         if (wide) {                                                                              \
@@ -656,7 +676,10 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
             if (c_bf16) MISPMM_BF16_LAUNCH(KERNEL, 4, true); else MISPMM_BF16_LAUNCH(KERNEL, 4, false); \
         }                                                                                        \
     } while (0)
-    if (bR == 16) MISPMM_BF16_PICK(bsr_mfma_bf16);
+    if (bR == 16 && !bsr_pipe && wide) {
+        if (c_bf16) hipLaunchKernelGGL((bsr_mfma_bf16<8, true, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
+        else hipLaunchKernelGGL((bsr_mfma_bf16<8, false, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
+    } else if (bR == 16) MISPMM_BF16_PICK(bsr_mfma_bf16);
     else MISPMM_BF16_PICK(bsr_mfma_bf16_b32);
 #undef MISPMM_BF16_PICK
 #undef MISPMM_BF16_LAUNCH

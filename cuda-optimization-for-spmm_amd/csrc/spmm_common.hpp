@@ -1,6 +1,8 @@
 // Device-side building blocks shared by the CSR / ELL / BSR / COO kernels.
 // gfx950 only: wave = 64 lanes, 16-byte global accesses, no CUDA-isms.
 #pragma once
+#include <cstdlib>
+
 #include "mispmm_internal.hpp"
 
 namespace mispmm {
@@ -120,8 +122,9 @@ struct AccFast {
 
 // Widest vector width usable for row-major dense operands B (ldb) and C (ldc) with N columns.
 inline int pick_vec(const float *B, uint32_t ldb, const float *C, uint32_t ldc, uint32_t N) {
-    if (N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) return 4;
-    if (N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && aligned8(B) && aligned8(C)) return 2;
+    static const int cap = [] { const char *e = getenv("MISPMM_VEC"); return e ? atoi(e) : 4; }();  // measurement aid
+    if (cap >= 4 && N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) return 4;
+    if (cap >= 2 && N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && aligned8(B) && aligned8(C)) return 2;
     return 1;
 }
 
