@@ -35,8 +35,8 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, int MINW = 1>
-__global__ __launch_bounds__(BLOCK, MINW) void row_gather_kernel(
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16>
+__global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
@@ -207,7 +207,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     return t;
 }
 
-template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16, int MINW = 1>
+template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16>
 void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
     const uint32_t cols_per_part = a.N / t.q;
     const uint32_t rb = ceil_div(a.M, BLOCK / G);
@@ -216,11 +216,11 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, MINW>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
                            static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, MINW>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
 }
 
@@ -237,7 +237,6 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     if (block == 64) launch_row_gather_b<G, VEC, Acc, Rows, 64, 8>(a, rows, t);
     else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256, 8>(a, rows, t);
     else if (umax == 16) launch_row_gather_b<G, VEC, Acc, Rows, 128, 16>(a, rows, t);
-    else if (umax == 88) launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, 8>(a, rows, t);   // experiment: cap at 64 VGPRs
     else launch_row_gather_b<G, VEC, Acc, Rows, 128, 8>(a, rows, t);
 }
 
