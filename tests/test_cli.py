@@ -143,3 +143,28 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
     assert all(r["correct"] == "1" for r in recs)
     best = max(float(r["rooflineFrac"]) for r in recs if "rooflineFrac" in r)
     assert best > 0.2, "steady-state HBM roofline fraction collapsed"
+
+
+def test_validate_tool_checks_cli_dumps(tmp_path, golden_dir):
+    """tools/validate.py (the reference's validate.py role): expected product from result.expect, *.out dumps
+    written by `cuspmm --save` compared against it; a corrupted dump is reported and fails the run."""
+    import shutil
+    import sys
+    d = tmp_path / "small_32x32"
+    shutil.copytree(os.path.join(golden_dir, "small_32x32"), d)
+    run_cli("--csr", "--cpu-only", "-d", str(d), "--save", str(d / "csr_cpu.out"))
+    run_cli("--coo", "--cpu-only", "-d", str(d), "--save", str(d / "coo_cpu.out"))
+    tool = os.path.join(ROOT, "tools", "validate.py")
+    p = subprocess.run([sys.executable, tool, str(d), "--rtol", "1e-5", "--atol", "1e-6"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("matches the expected result") == 2 and "Expect file found" in p.stdout
+    # without result.expect it is computed (float64) and written with 10 decimals, like the reference's
+    os.remove(d / "result.expect")
+    p = subprocess.run([sys.executable, tool, str(d), "--rtol", "1e-5", "--atol", "1e-6"], capture_output=True, text=True)
+    assert p.returncode == 0 and "Calculated expected result" in p.stdout
+    assert open(d / "result.expect").readline() == open(os.path.join(golden_dir, "small_32x32", "result.expect")).readline()
+    bad = np.loadtxt(d / "csr_cpu.out", skiprows=1, ndmin=2)
+    bad[3, 4] += 1.0
+    np.savetxt(d / "broken.out", bad)
+    p = subprocess.run([sys.executable, tool, str(d), "--rtol", "1e-5", "--atol", "1e-6"], capture_output=True, text=True)
+    assert p.returncode == 1 and "broken.out does NOT match" in p.stdout
