@@ -4,18 +4,13 @@
 
 #include <cassert>
 #include <chrono>
-#include <cstddef>
-#include <cstdint>
-#include <cstdio>
 #include <cstring>
 #include <fstream>
-#include <iostream>
 #include <sstream>
 #include <stdexcept>
-#include <string>
 #include <type_traits>
 
-#include "utils.hpp"
+#include "utils.hpp"  // <cstdint>, <iostream>, <string>, the record printer and the tolerances
 
 // element (r, c) of a matrix with B columns stored row-major / with A rows stored column-major
 #define RowMjIdx(r, c, B) ((size_t)(r) * (size_t)(B) + (size_t)(c))

@@ -3,7 +3,7 @@
 #pragma once
 
 #include "engine/engine_report.hpp"
-#include "formats/sparse_csr.hpp"
+#include "formats/sparse.hpp"
 
 namespace cuspmm {
 

@@ -1,0 +1,121 @@
+// The four sparse containers of the engine in one place.  Each keeps the public members and method
+// names of its counterpart in the reference (include/formats/sparse_{csr,coo,ell,bsr}.hpp) so code
+// written against those classes compiles here; storage comes from the C ABI (pinned host or device
+// memory, zero-filled), index type MT = uint32_t, value type DT = float or double.
+#pragma once
+
+#include "formats/dense.hpp"
+
+namespace cuspmm {
+
+// ----------------------------------------------------------------------------------------------------
+// CSR matrix (/root/reference/include/formats/sparse_csr.hpp:11-39).
+// `.csr` text file: "rows cols nnz" / rowPtrs (rows + 1) / colIdxs / values, one line each.
+template <typename _dataT, typename _metaT> class SparseMatrixCSR : public SparseMatrix<_dataT, _metaT> {
+  public:
+    using DT = _dataT;
+    using MT = _metaT;
+    MT *rowPtrs = nullptr;
+    MT *colIdxs = nullptr;
+
+    SparseMatrixCSR() = default;
+    explicit SparseMatrixCSR(std::string filePath);
+    SparseMatrixCSR(MT numRows, MT numCols, MT numNonZero, bool onDevice);
+    ~SparseMatrixCSR() override;
+
+    const char *formatName() const override { return "CSR"; }
+    SparseMatrixCSR<DT, MT> *copy2Device();
+    bool allocateSpace(bool onDevice);
+    DenseMatrix<DT, MT> *toDense();
+
+    template <typename U, typename M> friend std::ostream &operator<<(std::ostream &out, SparseMatrixCSR<U, M> &m);
+};
+
+// ----------------------------------------------------------------------------------------------------
+// COO matrix (/root/reference/include/formats/sparse_coo.hpp).  `.coo` text file: "rows cols nnz" then
+// one "row col value" line per entry, sorted row-major.
+template <typename _dataT, typename _metaT> class SparseMatrixCOO : public SparseMatrix<_dataT, _metaT> {
+  public:
+    using DT = _dataT;
+    using MT = _metaT;
+    MT *rowIdxs = nullptr;
+    MT *colIdxs = nullptr;
+    // device only: (numRows + 1) scratch the COO kernel fills with row boundaries
+    MT *rowBoundsWorkspace = nullptr;
+
+    SparseMatrixCOO() = default;
+    explicit SparseMatrixCOO(std::string filePath);
+    SparseMatrixCOO(MT numRows, MT numCols, MT numNonZero, bool onDevice);
+    ~SparseMatrixCOO() override;
+
+    const char *formatName() const override { return "COO"; }
+    SparseMatrixCOO<DT, MT> *copy2Device();
+    bool allocateSpace(bool onDevice);
+    DenseMatrix<DT, MT> *toDense();
+    // true when entries are sorted by row (the order the converter writes and the kernel needs)
+    bool isRowSorted() const;
+};
+
+// ----------------------------------------------------------------------------------------------------
+// ELL matrix in the reference's COLUMN-major layout (/root/reference/include/formats/sparse_ell.hpp:11-37):
+// rowIdxs / data are [numCols x maxColNnz], padding row index 0xFFFFFFFF (text "-1"), padding value 0.
+// The device copy additionally carries the row-major view the row-parallel HIP kernel consumes.
+template <typename _dataT, typename _metaT> class SparseMatrixELL : public SparseMatrix<_dataT, _metaT> {
+  public:
+    using DT = _dataT;
+    using MT = _metaT;
+    MT *rowIdxs = nullptr;
+    MT maxColNnz = 0;
+    // device only, built by copy2Device(): [numRows x rowWidth] column indices / values, padded
+    MT *rmColIdxs = nullptr;
+    DT *rmData = nullptr;
+    MT rowWidth = 0;
+
+    SparseMatrixELL() = default;
+    // files `<name>_rowind.ell` (header "rows cols nnz maxColNnz") and `<name>_values_colmajor.ell`
+    SparseMatrixELL(std::string rowindPath, std::string valuesPath);
+    SparseMatrixELL(MT numRows, MT numCols, MT numNonZero, MT maxColNnz, bool onDevice);
+    ~SparseMatrixELL() override;
+
+    const char *formatName() const override { return "ELL"; }
+    bool allocateSpace(bool onDevice);
+    SparseMatrixELL<DT, MT> *copy2Device();
+    DenseMatrix<DT, MT> *toDense();
+    size_t numSlots() const { return (size_t)this->numCols * (size_t)this->maxColNnz; }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// BSR matrix (/root/reference/include/formats/sparse_bsr.hpp:12-57).  `.bsr` text file:
+// "rows cols storedElements blockRowSize blockColSize numBlocks" / blockRowPtrs / blockColIdxs /
+// numBlocks * blockRowSize * blockColSize values (blocks row-major, block-CSR order).
+template <typename _dataT, typename _metaT> class SparseMatrixBSR : public SparseMatrix<_dataT, _metaT> {
+  public:
+    using DT = _dataT;
+    using MT = _metaT;
+    MT blockRowSize = 0;
+    MT blockColSize = 0;
+    MT numBlocks = 0;
+    MT *blockRowPtrs = nullptr;
+    MT *blockColIdxs = nullptr;
+    MT numBlockRows = 0;  // numRows / blockRowSize
+    MT numElements = 0;   // numBlocks * blockRowSize * blockColSize
+
+    SparseMatrixBSR() = default;
+    explicit SparseMatrixBSR(std::string filePath);
+    SparseMatrixBSR(MT numRows, MT numCols, MT numNonZero, MT blockRowSize, MT blockColSize, MT numBlocks,
+                    bool onDevice);
+    SparseMatrixBSR(SparseMatrixBSR<DT, MT> *target, bool onDevice);
+    ~SparseMatrixBSR() override;
+
+    const char *formatName() const override { return "BSR"; }
+    bool copyData(SparseMatrixBSR<DT, MT> *source, bool onDevice);
+    SparseMatrixBSR<DT, MT> *copy2Device();
+    void assertCheck();
+    void assertSameShape(SparseMatrixBSR<DT, MT> *target);
+    bool allocateSpace(bool onDevice);
+    // Blocks with at least one non-zero, block columns ascending (the reference declares this and throws).
+    static SparseMatrixBSR<DT, MT> *fromDense(DenseMatrix<DT, MT> *dense, MT blockRowSize, MT blockColSize);
+    DenseMatrix<DT, MT> *toDense();
+};
+
+}  // namespace cuspmm
