@@ -184,7 +184,8 @@ def run_single(args):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "SuiteSparse n4c6-b13 (reference data/large_25605) x seeded synthetic B",
         "config": {"workload": f"{args.matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
-                   "kernel": args.kernel, "acc_mode": args.acc, "launch": args.launch, "device": info["name"]},
+                   "kernel": args.kernel, "acc_mode": args.acc, "launch": args.launch, "device": info["name"],
+                   "uniform_row_hint": a.uniform_row_nnz if args.kernel in (0, 5) else 0},
         "achieved_hbm_GBps": round(abytes * args.steps / wall / 1e9, 1),
         "other_acc_mode": {"acc_mode": other, "launch_us": round(other_us, 3),
                            "roofline_frac": round(abytes / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),

@@ -6,6 +6,7 @@
 // width of the B rows that 1/P of the matrix rows touch (see k5 in spmm_csr.hip for the
 // traffic model).  `Rows` says where a row's entries live:
 //   CsrRows  entries [rowPtrs[r], rowPtrs[r+1])            (also a COO whose row bounds were built)
+//   UniformRows  CSR with a constant row length: entries [r * width, (r + 1) * width), no row pointers
 //   EllRows  entries [r * width, (r + 1) * width), column 0xFFFFFFFF = padding (dropped)
 #pragma once
 #include <cstdio>
@@ -23,6 +24,17 @@ struct CsrRows {
         const uint32_t s = rowPtrs[row];
         base = s;
         len = rowPtrs[row + 1] - s;
+    }
+};
+
+// CSR whose rows all hold exactly `width` entries (rowPtrs[r] == r * width): the row pointer array is
+// never read, one dependent memory hop less per wave (measured 4.25 -> 4.08 us on the headline).
+struct UniformRows {
+    uint32_t width;
+    static constexpr bool kPadded = false;
+    __device__ __forceinline__ void extent(uint32_t row, size_t &base, uint32_t &len) const {
+        base = static_cast<size_t>(row) * width;
+        len = width;
     }
 };
 

@@ -432,6 +432,25 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
 
 using namespace mispmm;
 
+extern "C" int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t rowNnz,
+                                      const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
+                                      float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_uniform: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (rowNnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_uniform: colIdxs or vals is null");
+    if (static_cast<uint64_t>(M) * rowNnz > 0xFFFFFFFFull) return fail(MISPMM_ERR_INVALID_ARG, "csr_uniform: more than 2^32 entries");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "csr_uniform: B of 2 GiB or more: use mispmm_csr_f32");
+    const RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc};
+    const int vec = pick_vec(B, ldb, C, ldc, N);
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{rowNnz}, vec);
+    else launch_row_gather_auto<AccFast>(ga, UniformRows{rowNnz}, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
 extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
                               const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
                               float *C, uint32_t ldc, int kernel, int acc_mode) {

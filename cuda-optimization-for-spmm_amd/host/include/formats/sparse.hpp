@@ -17,6 +17,9 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     using MT = _metaT;
     MT *rowPtrs = nullptr;
     MT *colIdxs = nullptr;
+    // > 0 on a device copy whose rows all hold exactly this many entries (checked on the host by
+    // copy2Device): lets the wrapper take mispmm_csr_uniform_f32, which never reads rowPtrs
+    MT uniformRowNnz = 0;
 
     SparseMatrixCSR() = default;
     explicit SparseMatrixCSR(std::string filePath);

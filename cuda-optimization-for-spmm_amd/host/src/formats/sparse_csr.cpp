@@ -46,6 +46,11 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     copyBuffer(d->rowPtrs, true, this->rowPtrs, false, ((size_t)this->numRows + 1) * sizeof(MT));
     copyBuffer(d->colIdxs, true, this->colIdxs, false, (size_t)this->numNonZero * sizeof(MT));
     copyBuffer(d->data, true, this->data, false, (size_t)this->numNonZero * sizeof(DT));
+    // structure check, once per upload: do all rows have the same length?
+    const MT w = this->numRows ? this->rowPtrs[1] - this->rowPtrs[0] : 0;
+    bool uniform = w > 0 && this->rowPtrs[0] == 0;
+    for (size_t r = 0; uniform && r <= this->numRows; ++r) uniform = this->rowPtrs[r] == (MT)(r * w);
+    d->uniformRowNnz = uniform ? w : 0;
     return d;
 }
 

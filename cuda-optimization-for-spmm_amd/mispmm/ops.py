@@ -40,6 +40,15 @@ def _dense_ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
 
 
+def uniform_row_nnz(row_ptrs):
+    """w if every row holds exactly w entries (rowPtrs[r] == r * w), else 0.  O(M) host scan."""
+    rp = np.asarray(row_ptrs, dtype=np.int64)
+    if rp.shape[0] < 2 or rp[0] != 0:
+        return 0
+    w = int(rp[1])
+    return w if w > 0 and np.array_equal(rp, np.arange(rp.shape[0], dtype=np.int64) * w) else 0
+
+
 @dataclass
 class DeviceCSR:
     num_rows: int
@@ -48,11 +57,12 @@ class DeviceCSR:
     row_ptrs: torch.Tensor
     col_idxs: torch.Tensor
     data: torch.Tensor
+    uniform_row_nnz: int = 0     # > 0: structure hint checked on the host when A was uploaded
 
     @staticmethod
     def from_host(csr, device="cuda"):
         return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
-                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device))
+                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs))
 
 
 @dataclass
@@ -114,13 +124,20 @@ def _out(m, n, b, out):
     return out
 
 
-def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None):
-    """C = A @ B.  a: DeviceCSR, b: [K, N] float32 device tensor (row-major, any row stride)."""
+def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=True):
+    """C = A @ B.  a: DeviceCSR, b: [K, N] float32 device tensor (row-major, any row stride).
+    With the default kernel (0 / 5) a CSR whose rows all have the same length goes through
+    mispmm_csr_uniform_f32 (no row-pointer fetch); use_hint=False forces the general entry point."""
     _require_gpu(a.row_ptrs, b)
     if b.shape[0] != a.num_cols:
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
+    if use_hint and a.uniform_row_nnz and int(kernel) in (0, 5) and a.num_cols * _dense_ld(b) * 4 <= 0x7FFFFFFF:
+        capi.check(capi.lib().mispmm_csr_uniform_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.uniform_row_nnz,
+                                                     _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c),
+                                                     _dense_ld(c), capi.ACC_MODES[acc]))
+        return c
     capi.check(capi.lib().mispmm_csr_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs),
                                          _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
                                          int(kernel), capi.ACC_MODES[acc]))

@@ -129,6 +129,15 @@ int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz,
                    uint32_t ldc, int kernel, int acc_mode);
 #define MISPMM_CSR_NUM_KERNELS 5
 
+/* Structure hint: a CSR whose rows ALL hold exactly rowNnz entries (rowPtrs[r] == r * rowNnz, e.g. the
+ * headline matrix n4c6-b13 with 14, or any ELL-shaped CSR).  Same arithmetic and results as
+ * mispmm_csr_f32 (kernel 5), but the row pointer array is never read: one dependent memory hop less
+ * per wave.  The caller vouches for the structure (the host layers check it once when A is copied to
+ * the device, an O(M) scan).  Returns MISPMM_ERR_UNSUPPORTED for a B of 2 GiB or more. */
+int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t rowNnz, const uint32_t *colIdxs,
+                           const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc,
+                           int acc_mode);
+
 /* -------------------------------------------------------------- ELL x dense */
 /* Row-major ELL: colIdxs/vals are [M x width], padding index 0xFFFFFFFF.
  * Replaces spmmELLWrapper1/2 (src/spmm/ell/spmm_ell_k1.cu:38-63,

@@ -84,6 +84,20 @@ def test_ell_host_conversion_edge_cases():
         ops.colmajor_ell_to_rowmajor(bad)
 
 
+def test_uniform_row_detection():
+    assert ops.uniform_row_nnz(datasets.load_csr("n4c6-b13").row_ptrs) == 14
+    assert ops.uniform_row_nnz(datasets.load_csr("ch7-6-b5").row_ptrs) == 6
+    assert ops.uniform_row_nnz(datasets.load_csr("qh1484").row_ptrs) == 0
+    assert ops.uniform_row_nnz(np.array([0, 2, 4, 7], np.uint32)) == 0
+    assert ops.uniform_row_nnz(np.array([0, 0, 0], np.uint32)) == 0          # all-empty rows: no hint
+    assert ops.uniform_row_nnz(np.array([0], np.uint32)) == 0
+    assert ops.uniform_row_nnz(np.array([1, 3, 5], np.uint32)) == 0          # does not start at 0
+    l = capi.lib()
+    one = ctypes.c_void_p(16)
+    assert l.mispmm_csr_uniform_f32(None, 4, 4, 2, None, one, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_uniform_f32(None, 4, 1 << 20, 2, one, one, one, 1024, 1024, one, 1024, 0) == capi.ERR_UNSUPPORTED
+
+
 def test_shard_rows_by_nnz():
     csr = datasets.load_csr("n4c6-b13")                      # 14 nnz in every row
     for parts in (1, 2, 4, 8):

@@ -108,6 +108,30 @@ def test_csr_strided_and_unaligned_operands(oracle, kernel):
         assert np.all(full[:, n:] == -7.0), "columns past N must not be written"
 
 
+@pytest.mark.parametrize("name,n", [("n4c6-b13", 128), ("ch7-6-b5", 64), ("n4c6-b13", 515), ("qh1484", 32)])
+def test_csr_uniform_row_hint_equals_general_path(oracle, name, n):
+    """mispmm_csr_uniform_f32 (row pointers never read) vs mispmm_csr_f32 vs the oracle: same bits.  The hint is
+    only taken for matrices whose rows really all have the same length (qh1484 does not: hint 0)."""
+    csr = datasets.load_csr(name)
+    a = ops.DeviceCSR.from_host(csr)
+    lens = np.diff(csr.row_ptrs.astype(np.int64))
+    assert a.uniform_row_nnz == (int(lens[0]) if np.all(lens == lens[0]) else 0)
+    assert (a.uniform_row_nnz > 0) == (name != "qh1484")
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for acc in ("reference", "fast"):
+        hinted = ops.spmm_csr(a, dev(b), acc=acc).cpu().numpy()
+        general = ops.spmm_csr(a, dev(b), acc=acc, use_hint=False).cpu().numpy()
+        assert np.array_equal(hinted, general)
+        if acc == "reference":
+            assert np.array_equal(hinted, ref)
+    # a poisoned row pointer array proves the hinted call does not read it
+    if a.uniform_row_nnz:
+        poisoned = ops.DeviceCSR(a.num_rows, a.num_cols, a.nnz, torch.full_like(a.row_ptrs, 0x7FFFFFFF), a.col_idxs, a.data,
+                                 a.uniform_row_nnz)
+        assert np.array_equal(ops.spmm_csr(poisoned, dev(b)).cpu().numpy(), ref)
+
+
 def test_csr_empty_and_overwrite():
     empty = formats.CSR(5, 9, np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
     c = torch.full((5, 16), 3.0, device="cuda")
