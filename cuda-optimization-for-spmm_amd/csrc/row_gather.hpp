@@ -47,8 +47,8 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16>
-__global__ __launch_bounds__(BLOCK) void row_gather_kernel(
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false>
+__global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
@@ -113,7 +113,68 @@ __global__ __launch_bounds__(BLOCK) void row_gather_kernel(
     };
     using FullBatch = std::integral_constant<int, U>;
 
-    if (!__any(row_len > static_cast<uint32_t>(U))) {
+    if constexpr (ROLL && G <= 16) {
+        // Rolling window: a row is walked in super-chunks of SC = 16 slots (each lane holds E = SC / G entries of
+        // it), U reads are kept in flight, and as soon as slot u has been consumed slot u + U is issued into the
+        // registers it freed -- the memory pipe never drains between batches of one row.
+        constexpr int SC = 16, E = SC / G;
+        uint32_t nxt_off[E];
+        float nxt_val[E];
+        auto fetch_super = [&](uint32_t base) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) fetch(row_base + min(base + e * G + lane, row_len - 1), nxt_off[e], nxt_val[e]);
+        };
+        if (row_len != 0) fetch_super(0);
+        for (uint32_t base = 0; base < row_len; base += SC) {
+            const uint32_t cnt = min(static_cast<uint32_t>(SC), row_len - base);
+            uint32_t my_off[E];
+            float my_val[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                my_off[e] = nxt_off[e];
+                my_val[e] = nxt_val[e];
+            }
+            if (base + SC < row_len) fetch_super(base + SC);
+            vec_t bv[U];
+            float av[U];
+            auto issue_one = [&](auto slot_tag, vec_t &b, float &a) {
+                constexpr int S = decltype(slot_tag)::value;
+                const uint32_t off = group_bcast<G, S % G>(my_off[S / G]);
+                const float c = __builtin_bit_cast(float, group_bcast<G, S % G>(__builtin_bit_cast(uint32_t, my_val[S / G])));
+                bool live = static_cast<uint32_t>(S) < cnt;
+                if constexpr (Rows::kPadded) live = live && off != kDropLoad;
+                a = live ? c : 0.f;
+                b = buffer_load_vec<VEC>(rsrc, live ? off + lane_off : kDropLoad, 0);
+            };
+            auto consume_one = [&](const vec_t &b, float a) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], a, vec_get<VEC>(b, v));
+            };
+            if (!__any(cnt > static_cast<uint32_t>(U))) {
+                static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, U>([&](auto s) { consume_one(bv[decltype(s)::value], av[decltype(s)::value]); });
+            } else {
+                static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, SC>([&](auto s) {
+                    constexpr int S = decltype(s)::value;
+                    consume_one(bv[S % U], av[S % U]);
+                    if constexpr (S + U < SC) {
+                        // the refill may not be hoisted above the consume it waits for: an empty asm that "rewrites"
+                        // the sums and clobbers memory sits between them (sched_barrier alone does not order the
+                        // side-effect-free multiply-adds at instruction selection)
+                        if constexpr (VEC == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+                        else if constexpr (VEC == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+                        else asm volatile("" : "+v"(acc[0]) : : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_one(std::integral_constant<int, S + U>{}, bv[S % U], av[S % U]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            }
+        }
+    } else if (!__any(row_len > static_cast<uint32_t>(U))) {
         // Every row of this wave fits one batch: one (col, val) fetch, U B reads in flight, one pass of
         // multiply-adds.  Wave-uniform branch.
         if (row_len != 0) {
@@ -198,11 +259,15 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     static const Env env;
     // default: column parts of 64 columns (16 lanes x 4) -- Q = N / 64 up to 8, P = 8 / Q row parts.
     // Measured on n4c6-b13: N = 128 -> 4 x 2 (4.25 us vs 4.41 us for 8 x 1); N = 512 -> 1 x 8 (15.5 us vs
-    // 16.0 / 17.0 / 18.8 us for 2 x 4 / 4 x 2 / 8 x 1).  Narrow or odd N keeps 8 x 1.
+    // 16.0 / 17.0 / 18.8 us for 2 x 4 / 4 x 2 / 8 x 1; two passes of 32-column parts: 15.3 us).  Narrow or odd N keeps 8 x 1.
     XcdTiling t{3u, 1u, true};
     if (vec >= 2 && N >= 128 && N % 64 == 0) {
         uint32_t q = 2;
         while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 64) == 0) q *= 2;
+        // N = 256: eight 32-column parts (every XCD sees all rows, fetches only its own 128-byte slice of each B
+        // row: compulsory fills only) beat 2 x 4 with 64-column parts -- 6.92 vs 7.33 us on n4c6-b13; at N = 128
+        // the same move (2 x 4, 32-column parts) loses, 4.15 vs 4.07 us.
+        if (q == 4 && N == 256) q = 8;
         t.q = q;
         t.log2p = q == 2 ? 2u : q == 4 ? 1u : 0u;
     }
@@ -219,7 +284,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     return t;
 }
 
-template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16>
+template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16, bool ROLL = false>
 void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
     const uint32_t cols_per_part = a.N / t.q;
     const uint32_t rb = ceil_div(a.M, BLOCK / G);
@@ -228,11 +293,11 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
                            static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
 }
 
@@ -246,6 +311,13 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     // beats finishing a 14-entry row in one batch (same box, headline: 4.25 -> 4.21 us REFERENCE, 4.43 -> 3.78 us
     // FAST; K = 256: 8.15 -> 7.59 us; K = 512: 15.5 -> 14.7 us).  MISPMM_UMAX=16 restores the deep batch.
     static const int umax = [] { const char *e = getenv("MISPMM_UMAX"); return e ? atoi(e) : 8; }();
+    // Rolling refill (G <= 16): measured on n4c6-b13, REFERENCE / FAST us: N = 128 4.06 -> 4.00 / 3.69 -> 3.70,
+    // N = 256 7.01 -> 6.79 / 6.65 -> 6.23, N = 512 14.38 -> 13.96 / 14.05 -> 13.82; 12 reads in flight instead of 8
+    // changed nothing.  MISPMM_ROLL=0 restores the batch-at-a-time body.
+    static const int roll = [] { const char *e = getenv("MISPMM_ROLL"); return e ? atoi(e) : 1; }();
+    if constexpr (G <= 16) {
+        if (roll) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true>(a, rows, t);
+    }
     if (block == 64) launch_row_gather_b<G, VEC, Acc, Rows, 64, 8>(a, rows, t);
     else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256, 8>(a, rows, t);
     else if (umax == 16) launch_row_gather_b<G, VEC, Acc, Rows, 128, 16>(a, rows, t);
@@ -256,7 +328,8 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
 template <class Acc, class Rows>
 void launch_row_gather_auto(const RowGatherArgs &a, const Rows &rows, int vec) {
     const XcdTiling t = xcd_tiling(a.N, vec);
-    const int g = pick_group(a.N / t.q, vec);
+    static const int group_env = [] { const char *e = getenv("MISPMM_GROUP"); return e ? atoi(e) : 0; }();  // measurement aid
+    const int g = group_env ? group_env : pick_group(a.N / t.q, vec);
 #define MISPMM_RG_CASE(GG, VV)                                     \
     if (g == GG && vec == VV) {                                    \
         launch_row_gather<GG, VV, Acc, Rows>(a, rows, t);          \

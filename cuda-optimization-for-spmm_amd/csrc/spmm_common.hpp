@@ -1,6 +1,7 @@
 // Device-side building blocks shared by the CSR / ELL / BSR / COO kernels.
 // gfx950 only: wave = 64 lanes, 16-byte global accesses, no CUDA-isms.
 #pragma once
+#include <type_traits>
 #include <cstdlib>
 
 #include "mispmm_internal.hpp"
@@ -91,6 +92,30 @@ __device__ __forceinline__ void buffer_store_vec_sc1(rsrc_t rsrc, uint32_t voffs
 // ---- accumulation policies (mispmm.h: enum mispmm_acc_mode) -----------------------------------
 // This library is compiled with -ffp-contract=off, so `a * b` followed by `+` stays two
 // roundings exactly as written; the fused form is spelled __builtin_fmaf.
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [BEGIN, END)
+template <int BEGIN, int END, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (BEGIN < END) {
+        f(std::integral_constant<int, BEGIN>{});
+        static_for<BEGIN + 1, END>(f);
+    }
+}
+
+// Lane SRC of every G-lane group to the whole group, SRC known at compile time: one DPP move
+// (row_newbcast, ctrl 0x150 + lane of the 16-lane row) instead of an LDS-crossbar permute, so the value
+// needs no register until the instruction that uses it.  G = 8: two groups share a DPP row.
+template <int G, int SRC>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
+    static_assert(G == 8 || G == 16, "row_newbcast works inside one 16-lane row");
+    if constexpr (G == 16) {
+        return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, false));
+    } else {
+        const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + 8 + SRC, 0xf, 0xf, false);
+        return static_cast<uint32_t>((threadIdx.x & 8u) ? hi : lo);
+    }
+}
 
 // Reference CSR: fp32 product, double running sum, one final rounding
 // (/root/reference/src/spmm/csr/spmm_csr.cpp:20-25 with AccT = double).

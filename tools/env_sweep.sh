@@ -1,0 +1,9 @@
+#!/bin/bash
+# Same workload, several environment-selected launch variants, one process each (the knobs are read once per
+# process).  tools/env_sweep.sh <k-cols> "<VAR=val ...>" "<VAR=val ...>" ...   ("-" = defaults)
+K=$1; shift
+for V in "$@"; do
+  echo "== K=$K variant: $V"
+  if [ "$V" = "-" ]; then V=""; fi
+  env $V timeout -k 10 120 python3 tools/kernel_sweep.py --kernels 5 --k-cols "$K" --iters 300 --rounds 5 2>&1 | grep -v "^$" || exit 1
+done
