@@ -74,7 +74,22 @@ def cpu_baseline(csr, b, budget_s, gpu_result, acc):
         orc.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
         times.append(time.perf_counter() - t0)
     best = min(times)
+    # the same engine with its row loop split over the host cores this process may use (the reference is
+    # single-threaded; this is the "host cores" column of SURVEY.md section 8(d)), a few seconds of it
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    mt = orc.spmm_csr_mt(csr.row_ptrs, csr.col_idxs, csr.data, b, threads)
+    if not np.array_equal(mt, ref):
+        raise SystemExit("bench: threaded CPU engine differs from the sequential one")
+    mt_times, t_end = [], time.perf_counter() + min(3.0, budget_s)
+    while time.perf_counter() < t_end and len(mt_times) < 5000:
+        t0 = time.perf_counter()
+        orc.spmm_csr_mt(csr.row_ptrs, csr.col_idxs, csr.data, b, threads)
+        mt_times.append(time.perf_counter() - t0)
+    mt_best = min(mt_times)
     return {"value": round(2.0 * csr.nnz * b.shape[1] / best / 1e9, 3), "unit": "GFLOP/s", "cores": 1,
+            "all_cores": {"value": round(2.0 * csr.nnz * b.shape[1] / mt_best / 1e9, 3), "unit": "GFLOP/s",
+                          "cores": threads, "ms_per_step": round(mt_best * 1e3, 4),
+                          "note": "same engine, row loop split with OpenMP, bit-identical result"},
             "kind": "port", "ms_per_step": round(best * 1e3, 4), "gpu_parity": parity,
             "sample": f"the full workload ({csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x K={b.shape[1]}), "
                       f"best of {len(times)} runs in {budget_s:.0f} s, oracle/spmm_oracle.c -O2, "
@@ -164,6 +179,28 @@ def run_single(args):
     step()                      # leave the timed mode's result in C for the parity check
     torch.cuda.synchronize()
 
+    # cold single shot (SURVEY.md 8(d) asks for it next to the steady-state figure): 1 GiB is written first so that
+    # neither the L2s nor the 256 MiB Infinity Cache hold A, B or C; median of 5; HIP events around ONE eager launch
+    # (an empty event pair costs a few microseconds itself, reported beside it)
+    cold, empty = [], []
+    flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            flush.fill_(1.0)
+            capi.check(l.mispmm_event_record(ev0, sp))
+            step()
+            capi.check(l.mispmm_event_record(ev1, sp))
+            stream.synchronize()
+            capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms_other)))
+            cold.append(ms_other.value * 1e3)
+            capi.check(l.mispmm_event_record(ev0, sp))
+            capi.check(l.mispmm_event_record(ev1, sp))
+            stream.synchronize()
+            capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms_other)))
+            empty.append(ms_other.value * 1e3)
+    del flush
+    cold_us, empty_us = sorted(cold)[2], sorted(empty)[2]
+
     flops = datasets.spmm_flops(csr.nnz, n)
     abytes = datasets.csr_algorithmic_bytes(csr, n)
     traffic = None     # PMC counters cannot be read from inside this process: committed rocprofv3 figure
@@ -190,6 +227,8 @@ def run_single(args):
         "other_acc_mode": {"acc_mode": other, "launch_us": round(other_us, 3),
                            "roofline_frac": round(abytes / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                            "note": "reference = the reference engine's fp64 accumulate (bit-exact); fast = fp32 fma chain (<= 1e-5)"},
+        "cold_single_shot": {"launch_us": round(cold_us, 2), "empty_event_pair_us": round(empty_us, 2),
+                             "note": "one eager launch after a 1 GiB cache flush, HIP events, median of 5 (not the metric)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": abytes, "launch_us": round(launch_s * 1e6, 3),

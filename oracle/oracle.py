@@ -36,6 +36,8 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_spmm_csr_f32.argtypes = [ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
         _lib.oracle_spmm_csr_f32.restype = None
+        _lib.oracle_spmm_csr_f32_mt.argtypes = [ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p, ctypes.c_int]
+        _lib.oracle_spmm_csr_f32_mt.restype = None
         _lib.oracle_spmm_coo_f32.argtypes = [ctypes.c_uint32, _u32p, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
         _lib.oracle_spmm_coo_f32.restype = None
         _lib.oracle_spmm_ell_colmajor_f32.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _u32p, _f32p, _f32p, ctypes.c_uint32, _f32p]
@@ -69,6 +71,19 @@ def spmm_csr(row_ptrs, col_idxs, data, b):
     n = bb.shape[1]
     c = np.zeros((m, n), dtype=np.float32)
     lib().oracle_spmm_csr_f32(m, rpp, cip, dap, bp, n, c.ctypes.data_as(_f32p))
+    return c
+
+
+def spmm_csr_mt(row_ptrs, col_idxs, data, b, threads):
+    """spmm_csr with the row loop split over `threads` host threads: bit-identical result."""
+    rp, rpp = _u32(row_ptrs)
+    ci, cip = _u32(col_idxs)
+    da, dap = _f32(data)
+    bb, bp = _f32(b)
+    m = rp.shape[0] - 1
+    n = bb.shape[1]
+    c = np.zeros((m, n), dtype=np.float32)
+    lib().oracle_spmm_csr_f32_mt(m, rpp, cip, dap, bp, n, c.ctypes.data_as(_f32p), int(threads))
     return c
 
 

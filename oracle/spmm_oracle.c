@@ -60,6 +60,31 @@ void oracle_spmm_csr_f32(uint32_t aNumRows, const uint32_t *rowPtrs,
     }
 }
 
+/* The same CSR engine with the row loop split over `threads` host threads (OpenMP static schedule).
+ * Rows are independent and each row's arithmetic is the sequential function's, so the result is
+ * bit-identical; this is the "all host cores" figure next to the sequential engine in bench.py
+ * (the reference itself is single-threaded: src/engine/engine.cpp:31 calls one spmm<F>Cpu). */
+void oracle_spmm_csr_f32_mt(uint32_t aNumRows, const uint32_t *rowPtrs,
+                            const uint32_t *colIdxs, const float *aData,
+                            const float *bData, uint32_t bNumCols, float *cData, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (int64_t r = 0; r < (int64_t)aNumRows; r++) {
+        uint32_t row_start = rowPtrs[r];
+        uint32_t row_end = rowPtrs[r + 1];
+        for (uint32_t c = 0; c < bNumCols; c++) {
+            double acc = 0.f;
+            for (uint32_t idx = row_start; idx < row_end; idx++) {
+                uint32_t k = colIdxs[idx];
+                float prod = aData[idx] * bData[(size_t)k * bNumCols + c];
+                acc += prod;
+            }
+            cData[(size_t)r * bNumCols + c] = (float)acc;
+        }
+    }
+}
+
 /* C += A_coo * B, C must be zeroed by the caller (the reference allocates a
  * zero-filled C: src/engine/engine.cpp:20, src/formats/dense.cu:234-251).
  * /root/reference/src/spmm/coo/spmm_coo.cpp:16-24. */
