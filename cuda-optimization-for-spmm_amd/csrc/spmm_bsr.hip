@@ -281,7 +281,7 @@ struct Bf16Frag {
 };
 
 template <int TPL, bool C_BF16, bool PIPE = true>
-__global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
+__global__ __launch_bounds__(256, PIPE ? 1 : 5) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
                                                      uint32_t b_bytes, uint32_t N, uint32_t ldb, void *__restrict__ Cv,
@@ -332,16 +332,19 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
         auto multiply = [&](const Bf16Frag<TPL> &f) {
             const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, f.araw);
 #pragma unroll
-            for (int t = 0; t < TPL; ++t) {
-                // tile t takes bf16 element t of every k row: dword t>>1, half t&1
-                u32x4_t packed;
+            for (int w = 0; w < TPL / 2; ++w) {
+                // tiles 2w and 2w+1 take the low and high bf16 of dword w of every k row; once both are packed the
+                // eight raw dwords are dead, so the regrouped operands never coexist with more than one dword column
+                u32x4_t even, odd;
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const uint32_t lo = f.braw[2 * p][t >> 1], hi = f.braw[2 * p + 1][t >> 1];
-                    packed[p] = (t & 1) ? __builtin_amdgcn_perm(hi, lo, 0x07060302u)   // {hi.h1, lo.h1}
-                                        : __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+                    const uint32_t lo = f.braw[2 * p][w], hi = f.braw[2 * p + 1][w];
+                    even[p] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+                    odd[p] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);   // {hi.h1, lo.h1}
                 }
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, packed), acc[t], 0, 0, 0);
+                acc[2 * w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, even), acc[2 * w], 0, 0, 0);
+                acc[2 * w + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, odd), acc[2 * w + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         if constexpr (PIPE) {
@@ -357,7 +360,10 @@ __global__ __launch_bounds__(256) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, 
                 col_next = col_next2;
             }
         } else {
-            // no register double buffer: half the fragment registers, more resident waves hide the latency
+            // no register double buffer: half the fragment registers, more resident waves hide the latency.
+            // Tried on top of this and measured no better (config 4, 11.5 us): A blocks and block columns fetched two
+            // iterations ahead (11.7 us, costs a resident wave), fewer resident workgroups so that the dispatcher
+            // balances the uneven block rows dynamically (12.4-13.5 us), write-through C stores (no gain).
             uint32_t col_cur = blockColIdxs[min(block_of(wave), last)];
             for (uint32_t pair = wave; pair < npairs; pair += 4) {
                 const uint32_t col_next = blockColIdxs[min(block_of(pair + 4), last)];
