@@ -122,7 +122,18 @@ __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
         float nxt_val[E];
         auto fetch_super = [&](uint32_t base) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) fetch(row_base + min(base + e * G + lane, row_len - 1), nxt_off[e], nxt_val[e]);
+            for (int e = 0; e < E; ++e) {
+                const uint32_t idx = base + e * G + lane;
+                fetch(row_base + min(idx, row_len - 1), nxt_off[e], nxt_val[e]);
+                // entries past the row end become dropped loads with a zero coefficient here, once per lane, so the
+                // per-slot code below needs no liveness test: a broadcast kDropLoad offset stays out of range after
+                // the lane's column offset is added (in a column-masked lane the sum wraps to 0: a harmless in-range
+                // read whose lane never stores)
+                if (idx >= row_len) {
+                    nxt_off[e] = kDropLoad;
+                    nxt_val[e] = 0.f;
+                }
+            }
         };
         if (row_len != 0) fetch_super(0);
         for (uint32_t base = 0; base < row_len; base += SC) {
@@ -141,14 +152,16 @@ __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
                 constexpr int S = decltype(slot_tag)::value;
                 const uint32_t off = group_bcast<G, S % G>(my_off[S / G]);
                 const float c = __builtin_bit_cast(float, group_bcast<G, S % G>(__builtin_bit_cast(uint32_t, my_val[S / G])));
-                bool live = static_cast<uint32_t>(S) < cnt;
-                if constexpr (Rows::kPadded) live = live && off != kDropLoad;
-                a = live ? c : 0.f;
-                b = buffer_load_vec<VEC>(rsrc, live ? off + lane_off : kDropLoad, 0);
+                a = c;
+                b = buffer_load_vec<VEC>(rsrc, off + lane_off, 0);
             };
             auto consume_one = [&](const vec_t &b, float a) {
+                if constexpr (VEC == 4 && std::is_same_v<Acc, AccRefWide>) {
+                    Acc::mac4(acc, a, vec_get<VEC>(b, 0), vec_get<VEC>(b, 1), vec_get<VEC>(b, 2), vec_get<VEC>(b, 3));
+                } else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], a, vec_get<VEC>(b, v));
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], a, vec_get<VEC>(b, v));
+                }
             };
             if (!__any(cnt > static_cast<uint32_t>(U))) {
                 static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
@@ -157,6 +170,8 @@ __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
             } else {
                 static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
                 __builtin_amdgcn_sched_barrier(0);
+                // (skipping the slots no row of the wave reaches -- 2 of 16 on the headline -- behind wave-uniform
+                // branches was measured slower: 3.74 -> 4.35 us; the straight-line body stays)
                 static_for<0, SC>([&](auto s) {
                     constexpr int S = decltype(s)::value;
                     consume_one(bv[S % U], av[S % U]);

@@ -109,10 +109,10 @@ template <int G, int SRC>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t x) {
     static_assert(G == 8 || G == 16, "row_newbcast works inside one 16-lane row");
     if constexpr (G == 16) {
-        return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, false));
+        return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, true));
     } else {
-        const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + 8 + SRC, 0xf, 0xf, false);
+        const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + SRC, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x150 + 8 + SRC, 0xf, 0xf, true);
         return static_cast<uint32_t>((threadIdx.x & 8u) ? hi : lo);
     }
 }
@@ -126,6 +126,17 @@ struct AccRefWide {
         acc += static_cast<double>(p);
     }
     static __device__ __forceinline__ float finish(T acc) { return static_cast<float>(acc); }
+    // four terms at once: the fp32 products as two packed multiplies (same IEEE rounding per element), then the
+    // widening adds
+    static __device__ __forceinline__ void mac4(T *acc, float a, float b0, float b1, float b2, float b3) {
+        using f2 = float __attribute__((ext_vector_type(2)));
+        const f2 av{a, a};
+        const f2 p01 = av * f2{b0, b1}, p23 = av * f2{b2, b3};
+        acc[0] += static_cast<double>(p01[0]);
+        acc[1] += static_cast<double>(p01[1]);
+        acc[2] += static_cast<double>(p23[0]);
+        acc[3] += static_cast<double>(p23[1]);
+    }
 };
 
 // Reference COO / ELL / BSR: fp32 product then fp32 add (e.g. spmm_ell.cpp:25).
