@@ -47,7 +47,7 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false>
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16>
 __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
@@ -117,7 +117,10 @@ __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
         // Rolling window: a row is walked in super-chunks of SC = 16 slots (each lane holds E = SC / G entries of
         // it), U reads are kept in flight, and as soon as slot u has been consumed slot u + U is issued into the
         // registers it freed -- the memory pipe never drains between batches of one row.
-        constexpr int SC = 16, E = SC / G;
+        // SLOTS < 16 (G = 16 only): rows known to hold at most SLOTS entries -- the uniform-row entry point picks it
+        // from the row length, so a 14-entry row issues 14 reads and no dropped ones
+        constexpr int SC = SLOTS, E = (SC + G - 1) / G;
+        static_assert(SLOTS == 16 || (G == 16 && SLOTS > U && SLOTS < 16), "SLOTS is a G = 16 specialisation");
         uint32_t nxt_off[E];
         float nxt_val[E];
         auto fetch_super = [&](uint32_t base) {
@@ -299,7 +302,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     return t;
 }
 
-template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16, bool ROLL = false>
+template <int G, int VEC, class Acc, class Rows, int BLOCK, int UMAX = 16, bool ROLL = false, int SLOTS = 16>
 void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTiling &t) {
     const uint32_t cols_per_part = a.N / t.q;
     const uint32_t rb = ceil_div(a.M, BLOCK / G);
@@ -308,11 +311,11 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
                            static_cast<uint32_t>(c_bytes), a.ldc);
     else
-        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
+        hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
 }
 
@@ -330,6 +333,15 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     // N = 256 7.01 -> 6.79 / 6.65 -> 6.23, N = 512 14.38 -> 13.96 / 14.05 -> 13.82; 12 reads in flight instead of 8
     // changed nothing.  MISPMM_ROLL=0 restores the batch-at-a-time body.
     static const int roll = [] { const char *e = getenv("MISPMM_ROLL"); return e ? atoi(e) : 1; }();
+    if constexpr (G == 16 && VEC == 4 && std::is_same_v<Rows, UniformRows>) {
+        // rows of 9..14 entries, all the same length: no dead slots (MISPMM_SLOTS=0 keeps the generic 16)
+        static const bool slots = [] { const char *e = getenv("MISPMM_SLOTS"); return !e || e[0] != '0'; }();
+        if (roll && slots) {
+            if (rows.width > 8 && rows.width <= 10) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 10>(a, rows, t);
+            if (rows.width > 10 && rows.width <= 12) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 12>(a, rows, t);
+            if (rows.width > 12 && rows.width <= 14) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 14>(a, rows, t);
+        }
+    }
     if constexpr (G <= 16) {
         if (roll) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true>(a, rows, t);
     }
