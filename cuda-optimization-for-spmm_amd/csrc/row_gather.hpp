@@ -48,7 +48,7 @@ struct EllRows {
 };
 
 template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16>
-__global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
+__global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? 5 : 1) void row_gather_kernel(
         // SLOTS < 16 (G = 16 only): rows known to hold at most SLOTS entries -- the uniform-row entry point picks it
         // from the row length, so a 14-entry row issues 14 reads and no dropped ones
         constexpr int SC = SLOTS, E = (SC + G - 1) / G;
-        static_assert(SLOTS == 16 || (G == 16 && SLOTS > U && SLOTS < 16), "SLOTS is a G = 16 specialisation");
+        static_assert(SLOTS == 16 || (G == 16 && SLOTS > U && (SLOTS < 16 || SLOTS == 32)), "SLOTS is a G = 16 specialisation");
         uint32_t nxt_off[E];
         float nxt_val[E];
         auto fetch_super = [&](uint32_t base) {
@@ -248,6 +248,7 @@ struct RowGatherArgs {
     uint32_t N, ldb;
     float *C;
     uint32_t ldc;
+    uint32_t mean_row_len = 0;  // nnz / M when the caller knows it (CSR, COO); 0 = unknown
 };
 
 // P x Q XCD grid and the C store flavour.  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
@@ -341,6 +342,15 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
             if (rows.width > 10 && rows.width <= 12) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 12>(a, rows, t);
             if (rows.width > 12 && rows.width <= 14) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 14>(a, rows, t);
         }
+    }
+    if constexpr (G == 16 && VEC == 4 && std::is_same_v<Rows, CsrRows>) {
+        // Long rows: a row's sum is sequential, so its time is (entries / reads in flight) x latency.  Matrices whose
+        // MEAN row already fills the 16-slot window (nnz >= 24 M; GL7d25: mean 29, longest 422) take 16 reads in
+        // flight over 32-slot super-chunks: 116 instead of 74 VGPRs, which such short grids do not miss.
+        // MISPMM_DEEP=0/1 forces the choice (measurement aid).
+        static const int deep_env = [] { const char *e = getenv("MISPMM_DEEP"); return e ? atoi(e) : -1; }();
+        const bool deep = deep_env >= 0 ? deep_env != 0 : a.mean_row_len >= 24;
+        if (roll && deep) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 16, true, 32>(a, rows, t);
     }
     if constexpr (G <= 16) {
         if (roll) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true>(a, rows, t);

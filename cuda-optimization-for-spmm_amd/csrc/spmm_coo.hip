@@ -169,7 +169,7 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     const int vec = pick_vec(B, ldb, C, ldc, N);
     if (rowPtrs_workspace && static_cast<uint64_t>(K) * ldb * 4u <= 0x7FFFFFFFull) {
         // with its row bounds materialised a sorted COO is a CSR: same kernel, same order of sums
-        const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc};
+        const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
         if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefF32>(ga, CsrRows{rowPtrs_workspace}, vec);
         else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs_workspace}, vec);
         MISPMM_LAUNCH_CHECK();

@@ -352,6 +352,114 @@ __global__ __launch_bounds__(256) void csr_k3(uint32_t M, const uint32_t *__rest
     }
 }
 
+// ------------------------------------------------------------------------------- csr_wave_deep
+// Long rows.  A row's sum is sequential by contract, so a row of L entries takes (L / reads in flight) x memory
+// latency however many waves the grid has; the lane-group kernels keep 8-16 reads in flight per row.  Here one WAVE
+// owns one row x (64 * VEC) columns and keeps W = 32 B-row reads in flight, refilled block by block (8 slots).  The
+// row's entries are staged once in a wave-private LDS strip as (byte offset of the B row, coefficient) pairs -- padding
+// to a multiple of 8 is (kDropLoad, 0), an exact no-op -- and every slot reads its pair back as an LDS broadcast, so
+// the body is a plain loop over blocks for any row length.  Chosen by the dispatcher when nnz >= 24 M.  GL7d25 (mean 29,
+// longest 422 entries), REFERENCE / FAST us: lane-group kernel 29.0 / 25.6, the same with 16 reads in flight 23.0 / 18.2,
+// this kernel 19.2 / 16.8.  Measured and no better: 64 reads in flight (24.3 / 21.1), one wave per 64 columns (19.0 /
+// 17.5), the pairs of the next block read from LDS one step early (21.7 / 17.2), other XCD tilings (23-35).
+template <int VEC, class Acc, int W = 32, int PHASE = 512>
+__global__ __launch_bounds__(256) void csr_wave_deep(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                                     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                                     const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                                     float *__restrict__ C, uint32_t ldc, uint32_t xcd_chunk) {
+    using vec_t = typename VecOf<VEC>::type;
+    using u2 = uint32_t __attribute__((ext_vector_type(2)));
+    constexpr int NBLK = W / 8;
+    __shared__ u2 strip[4][PHASE];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = xcd_block(blockIdx.x, xcd_chunk) * 4 + wave;
+    if (row >= M) return;  // wave-uniform exit; no workgroup barrier below
+    const uint32_t col0 = blockIdx.y * (64 * VEC) + lane * VEC;
+    const bool col_ok = col0 < N;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;
+    const uint32_t ldb4 = ldb * 4u;
+    const uint32_t start = rowPtrs[row], end = rowPtrs[row + 1];
+    u2 *e = strip[wave];
+    typename Acc::T acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0;
+
+    for (uint32_t base = start; base < end; base += PHASE) {
+        const uint32_t n = min(static_cast<uint32_t>(PHASE), end - base);
+        const uint32_t nblk = (n + 7u) / 8u;
+        for (uint32_t i = lane; i < nblk * 8u; i += 64) {
+            u2 pair{kDropLoad, 0u};
+            if (i < n) {
+                pair[0] = colIdxs[base + i] * ldb4;
+                pair[1] = __float_as_uint(vals[base + i]);
+            }
+            e[i] = pair;
+        }
+        // the strip is private to this wave and a wave's LDS operations complete in order; the wait keeps the
+        // compiler from moving the reads below ahead of the writes above
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        vec_t bv[W];
+        float av[W];
+        auto issue_block = [&](uint32_t blk, auto ring_tag) {
+            constexpr int R = decltype(ring_tag)::value;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const u2 pair = e[blk * 8u + t];  // same address in every lane: an LDS broadcast
+                av[R * 8 + t] = __uint_as_float(pair[1]);
+                bv[R * 8 + t] = buffer_load_vec<VEC>(rsrc, pair[0] + lane_off, 0);
+            }
+        };
+        auto consume_block = [&](auto ring_tag) {
+            constexpr int R = decltype(ring_tag)::value;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if constexpr (VEC == 4 && std::is_same_v<Acc, AccRefWide>) {
+                    Acc::mac4(acc, av[R * 8 + t], vec_get<VEC>(bv[R * 8 + t], 0), vec_get<VEC>(bv[R * 8 + t], 1),
+                              vec_get<VEC>(bv[R * 8 + t], 2), vec_get<VEC>(bv[R * 8 + t], 3));
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[R * 8 + t], vec_get<VEC>(bv[R * 8 + t], v));
+                }
+            }
+        };
+        static_for<0, NBLK>([&](auto r) {
+            if (static_cast<uint32_t>(decltype(r)::value) < nblk) issue_block(decltype(r)::value, r);
+        });
+        for (uint32_t b0 = 0; b0 < nblk; b0 += NBLK) {
+            static_for<0, NBLK>([&](auto r) {
+                const uint32_t blk = b0 + decltype(r)::value;
+                if (blk < nblk) {  // wave-uniform
+                    consume_block(r);
+                    if (blk + NBLK < nblk) {
+                        // the refill reuses the registers just consumed: keep it behind the sums (see row_gather.hpp)
+                        if constexpr (VEC == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+                        else if constexpr (VEC == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+                        else asm volatile("" : "+v"(acc[0]) : : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_block(blk + NBLK, r);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            });
+        }
+        // the next phase overwrites the strip: every read of this phase has been issued and, LDS being in order per
+        // wave, completes before those writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (col_ok) {
+        vec_t out;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
+        store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+    }
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 struct CsrArgs {
     hipStream_t stream;
@@ -361,6 +469,7 @@ struct CsrArgs {
     uint32_t N, ldb;
     float *C;
     uint32_t ldc;
+    uint32_t nnz = 0;
 };
 
 template <int G, int VEC, class Acc>
@@ -398,13 +507,36 @@ static void launch_wave(const CsrArgs &a) {
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }
 
+template <int VEC, class Acc>
+static void launch_wave_deep(const CsrArgs &a) {
+    const XcdGrid xg = xcd_grid(ceil_div(a.M, 4u));
+    dim3 grid(xg.grid, ceil_div(a.N, 64 * VEC));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    hipLaunchKernelGGL((csr_wave_deep<VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
+                       b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
+}
+
 template <class Acc>
 static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     // buffer offsets are 32-bit and bit 31 marks a dropped load: a B of 2 GiB or more takes the
     // 64-bit-address kernel
     const bool wide = static_cast<uint64_t>(a.K) * a.ldb * 4u > 0x7FFFFFFFull;
+    // kernel 5 on a matrix whose MEAN row is long (nnz >= 24 M): the deep wave-per-row kernel.  MISPMM_LONGROWS=0/1
+    // forces the choice (measurement aid; results do not depend on it).
+    static const int long_env = [] { const char *e = getenv("MISPMM_LONGROWS"); return e ? atoi(e) : -1; }();
+    const bool long_rows = long_env >= 0 ? long_env != 0 : (a.M != 0 && a.nnz / a.M >= 24);
+    if (kernel == 5 && !wide && long_rows) {
+        int v = vec;
+        while (v > 1 && 64u * (v / 2) >= a.N) v /= 2;
+        static const int vec_env = [] { const char *e = getenv("MISPMM_LONGROWS_VEC"); return e ? atoi(e) : 0; }();
+        if (vec_env > 0) v = min(v, vec_env);
+        if (v == 4) launch_wave_deep<4, Acc>(a);
+        else if (v == 2) launch_wave_deep<2, Acc>(a);
+        else launch_wave_deep<1, Acc>(a);
+        return;
+    }
     if (kernel == 5 && !wide) {
-        const RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc};
+        const RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc, a.M ? a.nnz / a.M : 0u};
         launch_row_gather_auto<Acc>(ga, CsrRows{a.rowPtrs}, vec);
         return;
     }
@@ -462,7 +594,7 @@ extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr: colIdxs or vals is null");
     if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
     if (kernel == MISPMM_KERNEL_AUTO) kernel = 5;
-    const CsrArgs a{as_stream(stream), M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc};
+    const CsrArgs a{as_stream(stream), M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, nnz};
     const int vec = pick_vec(B, ldb, C, ldc, N);
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_csr<AccRefWide>(a, kernel, vec);
     else launch_csr<AccFast>(a, kernel, vec);

@@ -2,6 +2,7 @@
 streams to the C ABI (data_ptr() in, data_ptr() out).  PyTorch is used for
 allocation and stream handles only -- all arithmetic happens in libmispmm.so."""
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -133,7 +134,7 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
-    if use_hint and a.uniform_row_nnz and int(kernel) in (0, 5) and a.num_cols * _dense_ld(b) * 4 <= 0x7FFFFFFF:
+    if use_hint and os.environ.get("MISPMM_NO_HINT") != "1" and a.uniform_row_nnz and int(kernel) in (0, 5) and a.num_cols * _dense_ld(b) * 4 <= 0x7FFFFFFF:
         capi.check(capi.lib().mispmm_csr_uniform_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.uniform_row_nnz,
                                                      _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c),
                                                      _dense_ld(c), capi.ACC_MODES[acc]))

@@ -75,6 +75,30 @@ def test_csr_matches_oracle(oracle, name, ns, kernel):
         assert_fast_close(cf, ref, abs_scale(csr, b))
 
 
+@pytest.mark.parametrize("n", [1, 64, 130, 256, 512])
+def test_csr_long_row_kernel(oracle, n):
+    """Mean row length >= 24 sends kernel 0/5 to the deep wave-per-row kernel (csr_wave_deep): rows of 0, 1, 7, 8, 9
+    entries, rows at and around its 512-entry LDS phase, a 1500-entry row; every vector width; bit-exact."""
+    lens = [0, 1, 7, 8, 9, 511, 512, 513, 1500, 0, 64, 33, 40, 25, 31, 200]
+    csr = random_csr(len(lens), 2000, lens, seed=11)
+    assert csr.nnz // csr.num_rows >= 24
+    a = ops.DeviceCSR.from_host(csr)
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for kernel in (0, 5):
+        c = ops.spmm_csr(a, dev(b), kernel=kernel, acc="reference").cpu().numpy()
+        assert np.array_equal(c, ref)
+        assert_fast_close(ops.spmm_csr(a, dev(b), kernel=kernel, acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+    # a strided C / B (ldb, ldc > N) through the same kernel
+    ld = n + 12
+    bw = torch.zeros((csr.num_cols, ld), dtype=torch.float32, device="cuda")
+    bw[:, :n] = dev(b)
+    cw = torch.full((csr.num_rows, ld), -7.0, dtype=torch.float32, device="cuda")
+    ops.spmm_csr(a, bw[:, :n], out=cw[:, :n], acc="reference")
+    assert np.array_equal(cw[:, :n].cpu().numpy(), ref)
+    assert torch.all(cw[:, n:] == -7.0)
+
+
 @pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
 def test_csr_ragged_rows_and_edges(oracle, kernel):
     """Empty rows, rows of 1, 17, 64, 65, 200 and 2500 entries (k2 re-stages LDS past 1024
