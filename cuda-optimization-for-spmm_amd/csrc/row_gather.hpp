@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
         // SLOTS < 16 (G = 16 only): rows known to hold at most SLOTS entries -- the uniform-row entry point picks it
         // from the row length, so a 14-entry row issues 14 reads and no dropped ones
         constexpr int SC = SLOTS, E = (SC + G - 1) / G;
-        static_assert(SLOTS == 16 || (G == 16 && SLOTS > U && (SLOTS < 16 || SLOTS == 32)), "SLOTS is a G = 16 specialisation");
+        static_assert(SLOTS == 16 || (SLOTS > U && SLOTS < 16) || (G == 16 && SLOTS == 32), "unsupported slot count");
         uint32_t nxt_off[E];
         float nxt_val[E];
         auto fetch_super = [&](uint32_t base) {
@@ -334,8 +334,9 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     // N = 256 7.01 -> 6.79 / 6.65 -> 6.23, N = 512 14.38 -> 13.96 / 14.05 -> 13.82; 12 reads in flight instead of 8
     // changed nothing.  MISPMM_ROLL=0 restores the batch-at-a-time body.
     static const int roll = [] { const char *e = getenv("MISPMM_ROLL"); return e ? atoi(e) : 1; }();
-    if constexpr (G == 16 && VEC == 4 && std::is_same_v<Rows, UniformRows>) {
-        // rows of 9..14 entries, all the same length: no dead slots (MISPMM_SLOTS=0 keeps the generic 16)
+    if constexpr ((G == 16 || G == 8) && VEC == 4 && (std::is_same_v<Rows, UniformRows> || std::is_same_v<Rows, EllRows>)) {
+        // rows of 9..14 slots, all the same length (uniform CSR, or ELL of that width): no dead slots
+        // (MISPMM_SLOTS=0 keeps the generic 16)
         static const bool slots = [] { const char *e = getenv("MISPMM_SLOTS"); return !e || e[0] != '0'; }();
         if (roll && slots) {
             if (rows.width > 8 && rows.width <= 10) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 10>(a, rows, t);
