@@ -280,13 +280,13 @@ struct Bf16Frag {
     uint32_t braw[8][TPL / 2];
 };
 
-template <int TPL, bool C_BF16, bool PIPE = true>
-__global__ __launch_bounds__(256, PIPE ? 1 : 5) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
+template <int TPL, bool C_BF16, bool PIPE = true, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, PIPE ? 1 : (WAVES == 4 ? 5 : 4)) void bsr_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ blockRowPtrs,
                                                      const uint32_t *__restrict__ blockColIdxs,
                                                      const uint16_t *__restrict__ blocks, const uint16_t *__restrict__ B,
                                                      uint32_t b_bytes, uint32_t N, uint32_t ldb, void *__restrict__ Cv,
                                                      uint32_t ldc, uint32_t xcd_chunk) {
-    __shared__ f32x4_t partial[3][TPL][64];  // waves 1..3, TPL tiles, one vector per lane
+    __shared__ f32x4_t partial[WAVES - 1][TPL][64];  // waves 1..WAVES-1, TPL tiles, one vector per lane
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t item = xcd_block(blockIdx.x, xcd_chunk);
@@ -348,13 +348,13 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 5) void bsr_mfma_bf16(uint32_t Mb, 
             }
         };
         if constexpr (PIPE) {
-            uint32_t col_next = blockColIdxs[min(block_of(wave + 4), last)];
+            uint32_t col_next = blockColIdxs[min(block_of(wave + WAVES), last)];
             Bf16Frag<TPL> cur;
             load_frag(wave, blockColIdxs[min(block_of(wave), last)], cur);
-            for (uint32_t pair = wave; pair < npairs; pair += 4) {
-                const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 8), last)];
+            for (uint32_t pair = wave; pair < npairs; pair += WAVES) {
+                const uint32_t col_next2 = blockColIdxs[min(block_of(pair + 2 * WAVES), last)];
                 Bf16Frag<TPL> nxt;
-                load_frag(pair + 4, col_next, nxt);
+                load_frag(pair + WAVES, col_next, nxt);
                 multiply(cur);
                 cur = nxt;
                 col_next = col_next2;
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 5) void bsr_mfma_bf16(uint32_t Mb, 
             // iterations ahead (11.7 us, costs a resident wave), fewer resident workgroups so that the dispatcher
             // balances the uneven block rows dynamically (12.4-13.5 us), write-through C stores (no gain).
             uint32_t col_cur = blockColIdxs[min(block_of(wave), last)];
-            for (uint32_t pair = wave; pair < npairs; pair += 4) {
-                const uint32_t col_next = blockColIdxs[min(block_of(pair + 4), last)];
+            for (uint32_t pair = wave; pair < npairs; pair += WAVES) {
+                const uint32_t col_next = blockColIdxs[min(block_of(pair + WAVES), last)];
                 Bf16Frag<TPL> cur;
                 load_frag(pair, col_cur, cur);
                 multiply(cur);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 5) void bsr_mfma_bf16(uint32_t Mb, 
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < WAVES - 1; ++w) {
 #pragma unroll
         for (int t = 0; t < TPL; ++t) acc[t] += partial[w][t][lane];
     }
@@ -682,6 +682,7 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
             if (c_bf16) MISPMM_BF16_LAUNCH(KERNEL, 4, true); else MISPMM_BF16_LAUNCH(KERNEL, 4, false); \
         }                                                                                        \
     } while (0)
+    // (8 waves per workgroup -- WAVES = 8, half the iterations per wave -- was measured slower: 13.2 vs 11.6 us)
     if (bR == 16 && !bsr_pipe && wide) {
         if (c_bf16) hipLaunchKernelGGL((bsr_mfma_bf16<8, true, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
         else hipLaunchKernelGGL((bsr_mfma_bf16<8, false, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
