@@ -75,6 +75,37 @@ def test_csr_matches_oracle(oracle, name, ns, kernel):
         assert_fast_close(cf, ref, abs_scale(csr, b))
 
 
+@pytest.mark.parametrize("width", [1, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 23])
+def test_uniform_rows_every_slot_count(oracle, width):
+    """mispmm_csr_uniform_f32 and ELL pick a slot count (10 / 12 / 14 / 16) from the row length; N = 128 runs 16-lane
+    groups, N = 256 8-lane groups, N = 100 / 20 the generic shapes.  Bit-exact against the oracle every time, and the
+    ELL of the same rows with padding holes."""
+    m, k = 333, 1200
+    csr = random_csr(m, k, [width] * m, seed=100 + width)
+    a = ops.DeviceCSR.from_host(csr)
+    assert a.uniform_row_nnz == width
+    rng = np.random.default_rng(width)
+    for n in (128, 256, 100, 20):
+        b = synth.dense_b(k, n)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        assert np.array_equal(ops.spmm_csr(a, dev(b), acc="reference").cpu().numpy(), ref), (width, n)
+        assert np.array_equal(ops.spmm_csr(a, dev(b), acc="reference", use_hint=False).cpu().numpy(), ref), (width, n)
+        assert_fast_close(ops.spmm_csr(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+        # ELL of that width with some entries turned into padding (anywhere in the row)
+        cols = csr.col_idxs.reshape(m, width).copy()
+        vals = csr.data.reshape(m, width).copy()
+        hole = rng.random((m, width)) < 0.2
+        cols[hole] = formats.ELL_PAD
+        vals[hole] = 0.0
+        ell = formats.ELLRowMajor(m, k, int((~hole).sum()), width, cols, vals)
+        ref_ell = np.zeros((m, n), np.float32)
+        for s_ in range(width):             # fp32 += in slot order, unfused, as spmmELLCpu sums a row
+            live = ~hole[:, s_]
+            ref_ell[live] = ref_ell[live] + vals[live, s_, None] * b[cols[live, s_]]
+        c = ops.spmm_ell(ops.DeviceELL.from_host(ell), dev(b)).cpu().numpy()
+        assert np.array_equal(c, ref_ell), (width, n)
+
+
 @pytest.mark.parametrize("n", [1, 64, 130, 256, 512])
 def test_csr_long_row_kernel(oracle, n):
     """Mean row length >= 24 sends kernel 0/5 to the deep wave-per-row kernel (csr_wave_deep): rows of 0, 1, 7, 8, 9
