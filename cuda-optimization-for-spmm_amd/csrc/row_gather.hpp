@@ -140,7 +140,6 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
         };
         if (row_len != 0) fetch_super(0);
         for (uint32_t base = 0; base < row_len; base += SC) {
-            const uint32_t cnt = min(static_cast<uint32_t>(SC), row_len - base);
             uint32_t my_off[E];
             float my_val[E];
 #pragma unroll
@@ -166,19 +165,31 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                     for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], a, vec_get<VEC>(b, v));
                 }
             };
-            if (!__any(cnt > static_cast<uint32_t>(U))) {
+            // is any live entry of this wave in a slot at or past `from`?  (entries past a row's end and ELL padding
+            // already carry kDropLoad, so trailing padding counts as absent)
+            auto live_from = [&](auto from_tag) {
+                constexpr int FROM = decltype(from_tag)::value;
+                bool live = false;
+                static_for<0, E>([&](auto e_tag) {
+                    constexpr int E0 = decltype(e_tag)::value * G;  // first slot held in register e
+                    if constexpr (E0 + G > FROM) {
+                        const bool in_range = (E0 >= FROM) || (lane >= static_cast<uint32_t>(FROM > E0 ? FROM - E0 : 0));
+                        live = live || (in_range && my_off[decltype(e_tag)::value] != kDropLoad);
+                    }
+                });
+                return __any(live);
+            };
+            // rolling body over SCX slots: U reads in flight, slot s + U issued as soon as slot s has been summed
+            auto roll = [&](auto scx_tag) {
+                constexpr int SCX = decltype(scx_tag)::value;
                 static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<0, U>([&](auto s) { consume_one(bv[decltype(s)::value], av[decltype(s)::value]); });
-            } else {
-                static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
-                __builtin_amdgcn_sched_barrier(0);
-                // (skipping the slots no row of the wave reaches -- 2 of 16 on the headline -- behind wave-uniform
-                // branches was measured slower: 3.74 -> 4.35 us; the straight-line body stays)
-                static_for<0, SC>([&](auto s) {
+                // (skipping single slots behind wave-uniform branches was measured slower, 3.74 -> 4.35 us on the
+                // headline; the body stays straight-line and only its length is chosen per super-chunk)
+                static_for<0, SCX>([&](auto s) {
                     constexpr int S = decltype(s)::value;
                     consume_one(bv[S % U], av[S % U]);
-                    if constexpr (S + U < SC) {
+                    if constexpr (S + U < SCX) {
                         // the refill may not be hoisted above the consume it waits for: an empty asm that "rewrites"
                         // the sums and clobbers memory sits between them (sched_barrier alone does not order the
                         // side-effect-free multiply-adds at instruction selection)
@@ -190,6 +201,20 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
+            };
+            if constexpr (Rows::kPadded) {
+                if (!live_from(std::integral_constant<int, 0>{})) continue;  // a super-chunk of padding only
+            }
+            if (!live_from(std::integral_constant<int, U>{})) {
+                static_for<0, U>([&](auto s) { issue_one(s, bv[decltype(s)::value], av[decltype(s)::value]); });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, U>([&](auto s) { consume_one(bv[decltype(s)::value], av[decltype(s)::value]); });
+            } else if constexpr (SC == 16) {
+                // ragged rows: three quarters of the slots when no row of the wave reaches slot 12
+                if (!live_from(std::integral_constant<int, 12>{})) roll(std::integral_constant<int, 12>{});
+                else roll(std::integral_constant<int, 16>{});
+            } else {
+                roll(std::integral_constant<int, SC>{});
             }
         }
     } else if (!__any(row_len > static_cast<uint32_t>(U))) {
