@@ -150,6 +150,15 @@ static void launch_coo_v(const CooArgs &a, int vec) {
 
 using namespace mispmm;
 
+extern "C" int mispmm_coo_row_bounds(mispmm_stream_t stream, uint32_t M, uint32_t nnz, const uint32_t *rowIdxs,
+                                     uint32_t *rowPtrs_out) {
+    if (!rowPtrs_out) return fail(MISPMM_ERR_INVALID_ARG, "coo_row_bounds: output is null");
+    if (nnz != 0 && !rowIdxs) return fail(MISPMM_ERR_INVALID_ARG, "coo_row_bounds: rowIdxs is null");
+    hipLaunchKernelGGL(coo_row_bounds, dim3(ceil_div(nnz + 1, 256)), dim3(256), 0, as_stream(stream), M, nnz, rowIdxs, rowPtrs_out);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
 extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowIdxs,
                               const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
                               float *C, uint32_t ldc, uint32_t *rowPtrs_workspace, int kernel, int acc_mode) {
@@ -159,8 +168,9 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     if (M == 0 || N == 0) return MISPMM_OK;
     if (nnz != 0 && (!rowIdxs || !colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "coo: null index or value array");
     if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (kernel == 2 && !rowPtrs_workspace) return fail(MISPMM_ERR_INVALID_ARG, "coo: kernel 2 needs the prepared row boundaries");
     hipStream_t st = as_stream(stream);
-    if (rowPtrs_workspace) {
+    if (rowPtrs_workspace && kernel != 2) {
         hipLaunchKernelGGL(coo_row_bounds, dim3(ceil_div(nnz + 1, 256)), dim3(256), 0, st, M, nnz, rowIdxs,
                            rowPtrs_workspace);
         MISPMM_LAUNCH_CHECK();

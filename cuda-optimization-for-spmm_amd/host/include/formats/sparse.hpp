@@ -45,6 +45,7 @@ template <typename _dataT, typename _metaT> class SparseMatrixCOO : public Spars
     MT *colIdxs = nullptr;
     // device only: (numRows + 1) scratch the COO kernel fills with row boundaries
     MT *rowBoundsWorkspace = nullptr;
+    bool rowBoundsReady = false;  // set once the boundaries of this device copy have been written
 
     SparseMatrixCOO() = default;
     explicit SparseMatrixCOO(std::string filePath);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_coo_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _i, _i]),
+    "mispmm_coo_row_bounds": (_i, [_vp, _u32, _u32, _vp, _vp]),
     "mispmm_vendor_spmm_f32": (_i, [_vp, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32,
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mispmm_dense_transpose_f32": (_i, [_vp, _u32, _u32, _vp, _vp]),

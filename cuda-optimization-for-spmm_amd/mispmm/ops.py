@@ -170,10 +170,22 @@ def spmm_bsr(a, b, out=None, kernel=0, acc="reference", stream=None):
     return c
 
 
+def coo_row_bounds(a, stream=None):
+    """The (M+1)-entry row-boundary array of a row-sorted device COO (the once-per-upload analysis step)."""
+    _require_gpu(a.row_idxs)
+    ws = torch.empty(a.num_rows + 1, dtype=torch.int32, device=a.row_idxs.device)
+    capi.check(capi.lib().mispmm_coo_row_bounds(_stream_ptr(stream), a.num_rows, a.nnz, _p(a.row_idxs), _p(ws)))
+    return ws
+
+
 def spmm_coo(a, b, out=None, kernel=0, acc="reference", stream=None, workspace=True):
-    """workspace=True allocates the (M+1)-entry row-boundary scratch; False uses binary search."""
+    """workspace=True allocates the (M+1)-entry row-boundary scratch; False uses binary search; a tensor from
+    coo_row_bounds() is used as is (pass kernel=2 to skip rebuilding it)."""
     _require_gpu(a.row_idxs, b)
-    ws = torch.empty(a.num_rows + 1, dtype=torch.int32, device=b.device) if workspace else None
+    if isinstance(workspace, torch.Tensor):
+        ws = workspace
+    else:
+        ws = torch.empty(a.num_rows + 1, dtype=torch.int32, device=b.device) if workspace else None
     if b.shape[0] != a.num_cols:
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]

@@ -183,11 +183,18 @@ int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, u
  * non-decreasing).  Replaces spmmCOOWrapper1 (src/spmm/coo/spmm_coo_k1.cu:50-103)
  * without atomics.  rowPtrs_workspace: device scratch of (M + 1) uint32 the call
  * fills with row boundaries first; NULL makes every row group binary-search its
- * range instead (slower, no scratch).  kernel: 0 auto, 1 row-group gather. */
+ * range instead (slower, no scratch).  kernel: 0 auto, 1 row-group gather,
+ * 2 the same with the boundaries ALREADY in rowPtrs_workspace (written by an
+ * earlier kernel-1 call or by mispmm_coo_row_bounds for the same rowIdxs): one
+ * launch per SpMM instead of two -- the analysis step a format object does once
+ * at upload (SparseMatrixCOO::copy2Device in the host layer). */
 int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowIdxs,
                    const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
                    uint32_t ldc, uint32_t *rowPtrs_workspace, int kernel, int acc_mode);
-#define MISPMM_COO_NUM_KERNELS 1
+#define MISPMM_COO_NUM_KERNELS 2
+/* rowPtrs_out[r] = index of the first entry of row r (r = 0..M; rowPtrs_out[M] = nnz) for a COO sorted by row. */
+int mispmm_coo_row_bounds(mispmm_stream_t stream, uint32_t M, uint32_t nnz, const uint32_t *rowIdxs,
+                          uint32_t *rowPtrs_out);
 
 /* ------------------------------------------------------- vendor cross-check */
 /* rocSPARSE generic SpMM (alpha 1, beta 0, fp32) into C, timed as prolog (handle, descriptors,

@@ -106,7 +106,7 @@ def test_host_api_gpu(golden_dir):
 @pytest.mark.parametrize("d", ["small_32x32_generated", "small_210_generated"])
 def test_cli_full_engine_flow_on_gpu(golden_dir, d):
     g = os.path.join(golden_dir, d)
-    expected_kernels = {"CSR": ["0", "1", "2", "3", "4", "5", "-1"], "COO": ["0", "1", "-1"], "BSR": ["0", "1", "2"],
+    expected_kernels = {"CSR": ["0", "1", "2", "3", "4", "5", "-1"], "COO": ["0", "1", "2", "-1"], "BSR": ["0", "1", "2"],
                         "ELL": ["0", "1"]}
     p = run_cli("--csr", "--coo", "--bsr", "--ell", "--iters", "20", "-d", g)
     recs = records(p.stdout)

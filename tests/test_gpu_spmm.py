@@ -308,6 +308,27 @@ def test_ell_padding_anywhere_and_wide_rows(oracle):
     assert np.array_equal(c, ref)
 
 
+def test_coo_prepared_row_bounds(oracle):
+    """Kernel 2 = kernel 1 minus the per-call boundary pass: boundaries from mispmm_coo_row_bounds (or left behind by a
+    kernel-1 call) give the same bits; the boundaries themselves equal the CSR row pointers."""
+    for name, n in (("n4c6-b13", 128), ("qh1484", 64), ("GL7d25", 32)):
+        csr = datasets.load_csr(name)
+        coo = formats.csr_to_coo(csr)
+        a = ops.DeviceCOO.from_host(coo)
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, b)
+        ws = ops.coo_row_bounds(a)
+        assert np.array_equal(ws.cpu().numpy().astype(np.uint32), csr.row_ptrs)
+        for acc in ("reference", "fast"):
+            c1 = ops.spmm_coo(a, dev(b), kernel=1, acc=acc).cpu().numpy()
+            c2 = ops.spmm_coo(a, dev(b), kernel=2, acc=acc, workspace=ws).cpu().numpy()
+            assert np.array_equal(c1, c2)
+            if acc == "reference":
+                assert np.array_equal(c2, ref)
+    with pytest.raises(capi.MispmmError):
+        ops.spmm_coo(a, dev(b), kernel=2, workspace=False)
+
+
 @pytest.mark.parametrize("workspace", [True, False])
 @pytest.mark.parametrize("name,ns", [("Hamrle1", [5, 32]), ("qh1484", [64]), ("n4c6-b13", [128]), ("GL7d25", [30])])
 def test_coo_matches_oracle(oracle, name, ns, workspace):
