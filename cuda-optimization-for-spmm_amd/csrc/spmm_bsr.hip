@@ -193,13 +193,15 @@ __global__ __launch_bounds__(256) void bsr_rowblock(uint32_t Mb, uint32_t nCT, c
 }
 
 // ---------------------------------------------------------------------------------- bsr_mfma_f32
-// Work item = (block row R, 64-column super-tile st); one wave each, 4 per workgroup.
+// Work item = (block row R, 64-column super-tile st) = one WORKGROUP; its 4 waves take the block row's blocks
+// round-robin (block bs + wave, + 4, ...), each keeps a partial 16 x 64 tile and the partials are summed through
+// LDS in fixed wave order (deterministic).  With one wave per block row the longest block row (54 blocks on
+// ACTIVSg10K) was one sequential chain of index -> B-row round trips: 65 us against a 16 us MFMA floor.
 // Lane l = (c = l & 15, g = l >> 4).  MFMA 16x16x4: A operand lane holds A[i = c][k = g],
 // B operand lane holds B[k = g][j = c]; D register r of lane l is D[row 4g + r][col c].
 // Step s of a block uses block columns 4s + g, so k runs over ascending columns.
-// The loop is software-pipelined two blocks deep: while block b is on the matrix pipe the A/B
-// fragments of b + 1 are in flight and the block column of b + 2 is being fetched -- without it a
-// wave spends a full index -> B-row round trip per block (measured 100 us vs the 14 us MFMA floor).
+// Each wave's loop is software-pipelined two blocks deep: while block b is on the matrix pipe the A/B
+// fragments of its next block are in flight and the block column of the one after is being fetched.
 struct F32Frag {
     float a[4];
     f32x4_t bv[4];
@@ -210,10 +212,11 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
                                                     const float *__restrict__ blocks, const float *__restrict__ B,
                                                     uint32_t b_bytes, uint32_t N, uint32_t ldb, float *__restrict__ C,
                                                     uint32_t ldc, uint32_t xcd_chunk) {
+    __shared__ f32x4_t partial[3][4][64];  // waves 1..3, 4 tiles, one vector per lane
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk) * 4 + wave;
-    if (item >= Mb * nST) return;  // wave-uniform
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk);
+    if (item >= Mb * nST) return;  // workgroup-uniform, before any barrier
     const uint32_t R = item / nST, st = item - R * nST;
     const uint32_t c = lane & 15, g = lane >> 4;
     const uint32_t ncol = st * 64 + c * 4;  // first of this lane's 4 interleaved output columns
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const uint32_t bs = blockRowPtrs[R], be = blockRowPtrs[R + 1];
-    if (bs < be) {
+    if (bs + wave < be) {
         const uint32_t last = be - 1;
         auto load_frag = [&](uint32_t b, uint32_t bcol, F32Frag &f) {  // b may run past `last`: clamped, unused
             const float *ablk = blocks + static_cast<size_t>(min(b, last)) * 256u + c * 16u + g;
@@ -238,13 +241,13 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
                 f.bv[s] = buffer_load_vec<4>(rsrc, voff + (4 * s + g) * ldb4, bcol * 16u * ldb4);
             }
         };
-        uint32_t col_next = blockColIdxs[min(bs + 1, last)];
+        uint32_t col_next = blockColIdxs[min(bs + wave + 4, last)];
         F32Frag cur;
-        load_frag(bs, blockColIdxs[bs], cur);
-        for (uint32_t b = bs; b < be; ++b) {
-            const uint32_t col_next2 = blockColIdxs[min(b + 2, last)];
+        load_frag(bs + wave, blockColIdxs[bs + wave], cur);
+        for (uint32_t b = bs + wave; b < be; b += 4) {
+            const uint32_t col_next2 = blockColIdxs[min(b + 8, last)];
             F32Frag nxt;
-            load_frag(b + 1, col_next, nxt);
+            load_frag(b + 4, col_next, nxt);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -253,6 +256,18 @@ __global__ __launch_bounds__(256) void bsr_mfma_f32(uint32_t Mb, uint32_t nST, c
             cur = nxt;
             col_next = col_next2;
         }
+    }
+    // fixed-order reduction of the four partial tiles: wave 0 adds waves 1, 2, 3 in that order
+    if (wave != 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) partial[wave - 1][t][lane] = acc[t];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += partial[w][t][lane];
     }
     if (ncol < N) {
 #pragma unroll
@@ -635,7 +650,7 @@ extern "C" int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uin
     if (kernel == MISPMM_KERNEL_AUTO) kernel = (mfma_ok && acc_mode == MISPMM_ACC_FAST) ? 2 : 1;
     if (kernel == 2) {
         const uint32_t nST = ceil_div(N, 64u);
-        const XcdGrid xg = xcd_grid(ceil_div(numBlockRows * nST, 4u));
+        const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, super-tile)
         hipLaunchKernelGGL(bsr_mfma_f32, dim3(xg.grid), dim3(256), 0, st, numBlockRows, nST, blockRowPtrs, blockColIdxs,
                            blocks, B, static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u), N, ldb, C, ldc, xg.chunk);
     } else {
