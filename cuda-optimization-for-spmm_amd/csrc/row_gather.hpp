@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                 const uint32_t off = group_bcast<G, S % G>(my_off[S / G]);
                 const float c = __builtin_bit_cast(float, group_bcast<G, S % G>(__builtin_bit_cast(uint32_t, my_val[S / G])));
                 a = c;
-                b = buffer_load_vec<VEC>(rsrc, off + lane_off, 0);
+                b = buffer_load_vec<VEC, MISPMM_B_LOAD_AUX>(rsrc, off + lane_off, 0);
             };
             auto consume_one = [&](const vec_t &b, float a) {
                 if constexpr (VEC == 4 && std::is_same_v<Acc, AccRefWide>) {

@@ -59,18 +59,22 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, uint32_t bytes) {
                                              0x00020000);
 }
 
-template <int VEC>
+// AUX = cache-policy bits of the load (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int VEC, int AUX = 0>
 __device__ __forceinline__ typename VecOf<VEC>::type buffer_load_vec(rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
     if constexpr (VEC == 1) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, 0));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset, soffset, AUX));
     } else if constexpr (VEC == 2) {
-        auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, 0);
+        auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, AUX);
         return __builtin_bit_cast(f32x2, r);
     } else {
-        auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+        auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, AUX);
         return __builtin_bit_cast(f32x4, r);
     }
 }
+#ifndef MISPMM_B_LOAD_AUX
+#define MISPMM_B_LOAD_AUX 0  // cache policy of the B-row reads of the row-gather kernel (measurement builds set 2 = nt)
+#endif
 
 // Write-through (sc1) vector store through a buffer descriptor: the bytes leave the XCD's L2 while
 // the kernel runs instead of being written back as dirty lines at the kernel boundary (measured on

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libmispmm.so")
+LIB_PATH = os.environ.get("MISPMM_LIB") or os.path.join(PKG_DIR, "libmispmm.so")   # MISPMM_LIB: A/B builds
 
 OK = 0
 ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3, -4, -5
