@@ -9,7 +9,7 @@ rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*|SQ_BUSY_CY
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 tools/run_bsr_bf16.py 200 > "$OUT/run.log" 2> "$OUT/trace.err"
 for f in $(find "$OUT/trace" -name '*kernel_stats.csv'); do cp "$f" "$OUT/kernel_stats.csv"; done
 i=0
-for PMC in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr"; do
+for PMC in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_REQ_sum TCC_EA0_RDREQ_sum SQ_INSTS_LDS SQ_INSTS_VMEM"; do
   i=$((i+1))
   rocprofv3 --pmc $PMC --output-format csv -d "$OUT/pmc$i" -- python3 tools/run_bsr_bf16.py 20 > /dev/null 2> "$OUT/pmc$i.err" || echo "pmc pass $i ($PMC) failed" >> "$OUT/pmc_errors.txt"
 done
