@@ -528,3 +528,16 @@ def test_vendor_check_agrees_within_fp32_accumulate_bound(oracle):
             err = np.abs(c.cpu().numpy().astype(np.float64) - ref)
             assert np.all(err <= longest * 2.0 ** -23 * scale + 1e-30), (fmt, float(np.max(err / (scale + 1e-30))))
             assert t[1].value > 0
+
+
+def test_uniform_entry_point_edges():
+    """rowNnz = 0 (every row empty) overwrites C with zeros; a B of 2 GiB or more is refused, not mis-addressed."""
+    l = capi.lib()
+    m, k, n = 70, 40, 24
+    b = dev(synth.dense_b(k, n))
+    c = torch.full((m, n), 5.0, dtype=torch.float32, device="cuda")
+    one = torch.zeros(1, dtype=torch.int32, device="cuda")
+    capi.check(l.mispmm_csr_uniform_f32(None, m, k, 0, ops._p(one), ops._p(one), ops._p(b), n, n, ops._p(c), n, 0))
+    assert torch.all(c == 0)
+    assert l.mispmm_csr_uniform_f32(None, m, 1 << 20, 1, ops._p(one), ops._p(one), ops._p(b), 1024, 1024, ops._p(c), 1024, 0) \
+        == capi.ERR_UNSUPPORTED
