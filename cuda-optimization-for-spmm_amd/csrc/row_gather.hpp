@@ -9,6 +9,7 @@
 //   UniformRows  CSR with a constant row length: entries [r * width, (r + 1) * width), no row pointers
 //   EllRows  entries [r * width, (r + 1) * width), column 0xFFFFFFFF = padding (dropped)
 #pragma once
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -16,6 +17,11 @@
 #include "spmm_common.hpp"
 
 namespace mispmm {
+
+#ifdef MISPMM_STAMPS
+// Diagnostic build only (tools/stamp_headline.py): every wave leaves s_memrealtime stamps (100 MHz) in a side buffer.
+static __device__ unsigned long long *mispmm_stamp_buf = nullptr;
+#endif
 
 struct CsrRows {
     const uint32_t *rowPtrs;
@@ -55,6 +61,10 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
     const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc) {
+#ifdef MISPMM_STAMPS
+    unsigned long long stamp[5];
+    stamp[0] = wall_clock64();
+#endif
     constexpr int GROUPS = BLOCK / G;
     constexpr int U = G < UMAX ? G : UMAX;  // B reads in flight per lane; a row of <= U entries is ONE batch
     using vec_t = typename VecOf<VEC>::type;
@@ -139,6 +149,10 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
             }
         };
         if (row_len != 0) fetch_super(0);
+#ifdef MISPMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[1] = wall_clock64();
+#endif
         for (uint32_t base = 0; base < row_len; base += SC) {
             uint32_t my_off[E];
             float my_val[E];
@@ -252,6 +266,10 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
             }
         }
     }
+#ifdef MISPMM_STAMPS
+    if constexpr (VEC == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+    stamp[2] = wall_clock64();
+#endif
     if (row_ok && col_ok) {
         vec_t out;
 #pragma unroll
@@ -262,6 +280,17 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
             store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
         }
     }
+#ifdef MISPMM_STAMPS
+    stamp[3] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[4] = wall_clock64();
+    if (mispmm_stamp_buf && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = mispmm_stamp_buf +
+            ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) o[i] = stamp[i];
+    }
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------------------

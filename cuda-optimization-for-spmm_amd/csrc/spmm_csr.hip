@@ -564,6 +564,14 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
 
 using namespace mispmm;
 
+#ifdef MISPMM_STAMPS
+// diagnostic build only: where the row-gather waves of THIS translation unit leave their stamps (8 x uint64 per wave)
+extern "C" int mispmm_debug_set_stamps(void *device_buffer) {
+    MISPMM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mispmm_stamp_buf), &device_buffer, sizeof(device_buffer)));
+    return MISPMM_OK;
+}
+#endif
+
 extern "C" int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t rowNnz,
                                       const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
                                       float *C, uint32_t ldc, int acc_mode) {
