@@ -1,6 +1,8 @@
 """Seeded random shapes through every format's HIP path, REFERENCE accumulate, bit-exact vs the oracle.
 Covers what the curated cases cannot enumerate: odd M / K / N, ragged and empty rows, rows longer than a
 chunk, padded leading dimensions, every CSR kernel id, square and rectangular BSR blocks."""
+import os
+
 import numpy as np
 import pytest
 
@@ -8,6 +10,7 @@ torch = pytest.importorskip("torch")
 from mispmm import formats, ops  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("MISPMM_FUZZ_SCALE", "1"))   # more seeds for an occasional deep run
 
 
 def rand_csr(rng, m, k):
@@ -45,7 +48,7 @@ def padded_out(r, c, rng):
     return buf[shift:shift + r * ld].view(r, ld)[:, :c]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_fuzz_csr_coo_ell(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     m, k, n = int(rng.integers(1, 300)), int(rng.integers(1, 500)), int(rng.integers(1, 300))
@@ -69,7 +72,7 @@ def test_fuzz_csr_coo_ell(oracle, seed):
     assert np.array_equal(out.cpu().numpy(), ref32), f"seed {seed} ELL"
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_fuzz_bsr(oracle, seed):
     rng = np.random.default_rng(2000 + seed)
     br = int(rng.choice([1, 2, 3, 4, 5, 8, 16, 32]))
@@ -89,7 +92,7 @@ def test_fuzz_bsr(oracle, seed):
     assert np.array_equal(out.cpu().numpy(), ref), f"seed {seed} BSR {br}x{bc} Mb={mb} Kb={kb} N={n}"
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * SCALE))
 def test_fuzz_bsr_mfma(oracle, seed):
     """Random 16x16 / 32x32 block structures (empty block rows, odd block counts, unsorted block columns,
     N not a multiple of the 64 / 128-column super-tiles) through the fp32 and bf16 MFMA kernels."""
