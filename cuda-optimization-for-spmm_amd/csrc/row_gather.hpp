@@ -336,7 +336,7 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     XcdTiling t{3u, 1u, true};
     if (vec >= 2 && N >= 128 && N % 64 == 0) {
         uint32_t q = 2;
-        while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 64) == 0) q *= 2;
+        while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 32) == 0) q *= 2;  // parts of >= 64 columns, whole 32-column groups
         // N = 256: eight 32-column parts (every XCD sees all rows, fetches only its own 128-byte slice of each B
         // row: compulsory fills only) beat 2 x 4 with 64-column parts -- 6.92 vs 7.33 us on n4c6-b13; at N = 128
         // the same move (2 x 4, 32-column parts) loses, 4.15 vs 4.07 us.
@@ -422,7 +422,14 @@ template <class Acc, class Rows>
 void launch_row_gather_auto(const RowGatherArgs &a, const Rows &rows, int vec) {
     const XcdTiling t = xcd_tiling(a.N, vec);
     static const int group_env = [] { const char *e = getenv("MISPMM_GROUP"); return e ? atoi(e) : 0; }();  // measurement aid
-    const int g = group_env ? group_env : pick_group(a.N / t.q, vec);
+    // 16 or 8 lanes per row (64 or 32 columns at VEC = 4) whenever they tile the column part exactly: several
+    // sub-parts per XCD part (grid.y) instead of one wide, partly idle lane group -- and the rolling body, which
+    // exists for G <= 16 only (N = 96 / 192 / 384 ran 3.98 / 6.31 / 12.9 us with 32- and 64-lane groups)
+    const uint32_t cpp = a.N / t.q;
+    const int g = group_env ? group_env
+                  : (vec == 4 && cpp % 64 == 0) ? 16
+                  : (vec == 4 && cpp % 32 == 0) ? 8
+                                                : pick_group(cpp, vec);
 #define MISPMM_RG_CASE(GG, VV)                                     \
     if (g == GG && vec == VV) {                                    \
         launch_row_gather<GG, VV, Acc, Rows>(a, rows, t);          \
