@@ -154,7 +154,21 @@ __global__ __launch_bounds__(256) void bsr_rowblock(uint32_t Mb, uint32_t nCT, c
             areg[p] = idx < SUB ? sub[idx] : 0.f;
         }
     };
-    if (bs < be) load_block(bs);
+    // B rows arrive one step (4 block columns) ahead of the multiply-adds that use them, across block boundaries:
+    // with the reads issued inside the step that consumed them a wave paid one L2 round trip per 4 columns
+    // (config 4a: 86.9 -> 84.4 us; the block values through the scalar cache instead of LDS: 96.5 us.  What is left is
+    // imbalance: 2500 waves, 8 to 54 blocks each, 2.4 per SIMD, against a 28 us floor of the multiply + add stream).
+    auto issue_b = [&](uint32_t brow, uint32_t off_or_drop, vec_t (&dst)[4]) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dst[jj] = buffer_load_vec<VEC>(rsrc, off_or_drop, (brow + jj) * ldb4);
+    };
+    vec_t cur[4];
+    uint32_t brow_next = 0;
+    if (bs < be) {
+        load_block(bs);
+        brow_next = blockColIdxs[bs] * BD;
+        issue_b(brow_next, lane_off, cur);
+    }
     for (uint32_t b = bs; b < be; ++b) {
         float *slot = stage[wave][(b - bs) & 1];
 #pragma unroll
@@ -162,23 +176,27 @@ __global__ __launch_bounds__(256) void bsr_rowblock(uint32_t Mb, uint32_t nCT, c
             const uint32_t idx = p * 64 + lane;
             if (idx < SUB) slot[idx] = areg[p];
         }
-        const uint32_t brow0 = blockColIdxs[b] * BD;
-        if (b + 1 < be) load_block(b + 1);  // next block's values fly while this one is multiplied
+        const uint32_t brow0 = brow_next;
+        const bool more = b + 1 < be;  // wave-uniform
+        brow_next = more ? blockColIdxs[b + 1] * BD : 0u;
+        if (more) load_block(b + 1);  // next block's values fly while this one is multiplied
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ds_writes of this wave before its ds_reads
-#pragma unroll 1
-        for (int j0 = 0; j0 < BD; j0 += 4) {
-            vec_t bv[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bv[jj] = buffer_load_vec<VEC>(rsrc, lane_off, (brow0 + j0 + jj) * ldb4);
+        for (int j0 = 0; j0 < BD; j0 += 4) {
+            vec_t nxt[4];
+            if (j0 + 4 < BD) issue_b(brow0 + j0 + 4, lane_off, nxt);
+            else issue_b(brow_next, more ? lane_off : kDropLoad, nxt);  // first step of the next block (nothing past the row)
 #pragma unroll
             for (int i = 0; i < RS; ++i) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4 *>(slot + i * BD + j0);  // broadcast read
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[i][v], a4[jj], vec_get<VEC>(bv[jj], v));
+                    for (int v = 0; v < VEC; ++v) Acc::mac(acc[i][v], a4[jj], vec_get<VEC>(cur[jj], v));
                 }
             }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) cur[jj] = nxt[jj];
         }
     }
     if (col_ok) {
