@@ -1,8 +1,7 @@
 """Where does a wave of the headline launch spend its time?  Runs the PRODUCTION row-gather kernel from a diagnostic
 build of the library (-DMISPMM_STAMPS: s_memrealtime stamps, 100 MHz, into a side buffer) and prints percentiles.
 
-  cd cuda-optimization-for-spmm_amd && hipcc <HIPFLAGS> -DMISPMM_STAMPS -c csrc/spmm_csr.hip -o build_stamp/spmm_csr.o \\
-     && hipcc -shared ... -o libmispmm_stamps.so        
+  make -C cuda-optimization-for-spmm_amd stamps        (builds libmispmm_stamps.so next to libmispmm.so)
   MISPMM_LIB=.../libmispmm_stamps.so python tools/stamp_headline.py [--acc reference|fast] [--k-cols 128]
 GPU box only.  Stamps: 0 wave start, 1 (col, val) arrived, 2 last B row summed, 3 store issued, 4 store drained."""
 import argparse
