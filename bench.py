@@ -1,30 +1,41 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline SpMM measurement (BASELINE.json).
+"""bench.py -- the SpMM measurement of BASELINE.json, one JSON line per run.
 
-Workload: data/large_25605 (SuiteSparse n4c6-b13, 6300 x 25605, nnz 88 200) in CSR times a
-synthetic dense B (25605 x K, K = 128 fp32, seeded; see mispmm/synth.py).  One "step" = one
-full SpMM C = A @ B through the C ABI (mispmm_csr_f32), inputs resident in HBM.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config headline|2|3|4|5]
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N = 1 by default)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+One "step" = one full SpMM C = A @ B through the C ABI of libmispmm.so with A, B and C resident in HBM.
 
-N = 1: the K timed steps are captured once into a hipGraph on the bench stream and replayed
-(launch-bound otherwise: one step is a few microseconds), bracketed by torch.cuda.synchronize();
-`roofline.achieved` divides the algorithmic bytes by the mean per-launch time measured with HIP
-events on that same stream.
-N > 1: rows of A are split into N contiguous nnz-balanced ranges (one rank per GPU), B is
-broadcast once from rank 0 over RCCL before the timed region, every rank multiplies its slab
-each step, and the C row slabs are all-gathered with RCCL in buckets (--bucket steps per
-collective) on a second stream overlapped with the following steps.  `value` is end to end
-(kernels + gathers, max over ranks); `kernel_only` reports the same run's compute-stream time.
+  --config headline  large_25605 (n4c6-b13) CSR x dense K=128 fp32        (the BASELINE.json metric; default)
+           2         medium_4096 (stand-in delaunay_n12) CSR x K=128 fp32
+           3         large_25605 ELL x K=256 fp32
+           4         large_20000 (ACTIVSg10K) BSR block 16 x K=128 bf16 (MFMA)
+           5         large_25605 CSR x K=512 fp32  (row-sharded when --gpus N > 1)
+
+N = 1.  W eager warm-up steps, then the K timed steps are captured once into a hipGraph on the bench stream.
+A step lasts a few microseconds, so a single replay of a small K would time the launch latency of the graph and
+the clock ramp instead of the kernel: the graph is therefore replayed untimed for >= 50 ms (precondition) and
+then R times back to back inside one HIP-event pair, R chosen so that the timed region lasts >= 20 ms; that is
+repeated for 5 rounds.  A graph of fewer than 1000 launches holds the K steps several times over (two consecutive
+hipGraphLaunch calls leave the GPU idle for ~7 us: graph-API machinery, reported as `graph_of_exactly_steps_us`).  `ms_per_step`, `value` and `roofline` come from the MEDIAN round's event time divided by
+K * R launches; min and the spread are reported beside it; `replays` = R.  K and W are used exactly as passed.
+
+N > 1.  Started plainly (`python bench.py --gpus N`), this process spawns its N ranks itself (children, before
+it makes any GPU call); under torch.distributed.run it is one of the ranks.  Rows of A are cut into N contiguous
+nnz-balanced ranges, B is broadcast once (outside the timed region), every rank multiplies its slab each step
+and the C row slabs are exchanged in buckets: `allgather` (RCCL all_gather_into_tensor on a second stream) or
+`peer` (the kernel's slab is copied straight into every peer's C over xGMI through IPC-mapped buffers).  `value`
+is end to end (kernels + exchange, max over ranks); `kernel_only` re-runs the steps with C left row-sharded.
 Strong scaling: the total work is fixed as N grows.
 
-Prints ONE JSON line on rank 0.
+The CPU leg (`cpu_baseline`) is the oracle under oracle/ -- a port of the reference's sequential CPU engine --
+timed on this host with 1 thread, and also the checker of the GPU result that was just timed: a mismatch
+refuses to print a number.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,212 +45,445 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cuda-optimization-for-spmm_amd"))
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, same guide
+PRECONDITION_S = 0.05            # untimed replays before the timed region
+TIMED_S = 0.02                   # minimum length of one timed round
+ROUNDS = 5
+MIN_GRAPH_NODES = 1000           # launches per captured graph (the K steps are captured ceil(1000 / K) times over)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
-    p.add_argument("--matrix", default="n4c6-b13")
-    p.add_argument("--k-cols", type=int, default=128, help="columns of the dense operand (BASELINE 'K')")
-    p.add_argument("--kernel", type=int, default=0, help="CSR kernel id (0 = library default)")
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--config", default="headline", choices=["headline", "2", "3", "4", "5"])
+    p.add_argument("--matrix", default=None, help="override the configuration's matrix (packed name under data/)")
+    p.add_argument("--k-cols", type=int, default=None, help="override the columns of the dense operand (BASELINE 'K')")
+    p.add_argument("--kernel", type=int, default=0, help="kernel id of the format's entry point (0 = library default)")
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
-    p.add_argument("--bucket", type=int, default=16, help="N>1: steps per C-slab all-gather")
+    p.add_argument("--bucket", type=int, default=16, help="N>1: steps per C-slab exchange")
+    p.add_argument("--exchange", default="both", choices=["allgather", "peer", "both"],
+                   help="N>1: how C slabs travel; `both` measures the two and reports the faster as `value`")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the other accumulate mode and the cold single shot (profiling passes use this)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget")
     return p.parse_args()
 
 
-def cpu_baseline(csr, b, budget_s, gpu_result, acc):
-    """The CPU leg: the oracle (a port of the reference's sequential spmmCSRCpu) timed on this
-    host with 1 thread -- and, since its output is at hand, used as the checker of the GPU result
-    that was just timed (bit-exact in REFERENCE mode, 1e-5 of sum|a||b| in FAST mode)."""
+# ------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One BASELINE configuration on one GPU: operands resident on the device, `step()` enqueues one SpMM."""
+    fmt = "csr"
+    dtype = "f32"
+
+    def step(self, stream, acc=None):
+        raise NotImplementedError
+
+    def host_result(self):
+        raise NotImplementedError
+
+
+class CsrWorkload(Workload):
+    fmt = "csr"
+
+    def __init__(self, args, matrix, n, label):
+        import torch
+        from mispmm import datasets, ops, synth
+        self.args, self.n, self.label, self.matrix = args, n, label, matrix
+        self.csr = datasets.load_csr(matrix)
+        self.b_host = synth.dense_b(self.csr.num_cols, n)
+        self.a = ops.DeviceCSR.from_host(self.csr)
+        self.b = torch.from_numpy(self.b_host).cuda()
+        self.c = torch.empty((self.csr.num_rows, n), dtype=torch.float32, device="cuda")
+        self.flops = datasets.spmm_flops(self.csr.nnz, n)
+        self.abytes = datasets.csr_algorithmic_bytes(self.csr, n)
+        self.workload = (f"{matrix} CSR {self.csr.num_rows}x{self.csr.num_cols} nnz {self.csr.nnz} x dense K={n} fp32")
+        self.extra_config = {"uniform_row_hint": self.a.uniform_row_nnz if args.kernel in (0, 5) else 0}
+        self.has_fast = True
+
+    def step(self, stream, acc=None):
+        from mispmm import ops
+        ops.spmm_csr(self.a, self.b, out=self.c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
+
+    def host_result(self):
+        return self.c.cpu().numpy()
+
+    def oracle_call(self, orc):
+        c = self.csr
+        return lambda: orc.spmm_csr(c.row_ptrs, c.col_idxs, c.data, self.b_host)
+
+    def oracle_threads_call(self, orc, threads):
+        c = self.csr
+        return lambda: orc.spmm_csr_mt(c.row_ptrs, c.col_idxs, c.data, self.b_host, threads)
+
+    def check(self, orc, got, ref, acc):
+        if acc == "reference":
+            return "bit-exact" if np.array_equal(got, ref) else "MISMATCH"
+        c = self.csr
+        scale = orc.spmm_csr(c.row_ptrs, c.col_idxs, np.abs(c.data), np.abs(self.b_host)).astype(np.float64)
+        return "within 1e-5" if np.all(np.abs(got.astype(np.float64) - ref) <= 1e-5 * scale + 1e-37) else "MISMATCH"
+
+
+class EllWorkload(Workload):
+    fmt = "ell"
+
+    def __init__(self, args, matrix, n, label):
+        import torch
+        from mispmm import datasets, formats, ops, synth
+        self.args, self.n, self.label, self.matrix = args, n, label, matrix
+        self.csr = datasets.load_csr(matrix)
+        self.ellc = formats.csr_to_ell_colmajor(self.csr)            # the reference's on-disk / in-class layout
+        self.b_host = synth.dense_b(self.csr.num_cols, n)
+        self.a = ops.DeviceELL.from_host(self.ellc)
+        self.b = torch.from_numpy(self.b_host).cuda()
+        self.c = torch.empty((self.csr.num_rows, n), dtype=torch.float32, device="cuda")
+        self.flops = datasets.spmm_flops(self.csr.nnz, n)
+        self.abytes = datasets.ell_algorithmic_bytes(self.csr.num_rows, self.a.width, self.csr.num_cols, n)
+        self.workload = (f"{matrix} ELL {self.csr.num_rows}x{self.csr.num_cols} width {self.a.width} "
+                         f"(nnz {self.csr.nnz}) x dense K={n} fp32")
+        self.extra_config = {"ell_width": self.a.width}
+        self.has_fast = True
+
+    def step(self, stream, acc=None):
+        from mispmm import ops
+        ops.spmm_ell(self.a, self.b, out=self.c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
+
+    def host_result(self):
+        return self.c.cpu().numpy()
+
+    def oracle_call(self, orc):
+        e = self.ellc
+        return lambda: orc.spmm_ell_colmajor(e.num_rows, e.row_idxs, e.data, self.b_host)
+
+    def oracle_threads_call(self, orc, threads):
+        return None
+
+    def check(self, orc, got, ref, acc):
+        if acc == "reference":
+            return "bit-exact" if np.array_equal(got, ref) else "MISMATCH"
+        c = self.csr
+        scale = orc.spmm_csr(c.row_ptrs, c.col_idxs, np.abs(c.data), np.abs(self.b_host)).astype(np.float64)
+        return "within 1e-5" if np.all(np.abs(got.astype(np.float64) - ref) <= 1e-5 * scale + 1e-37) else "MISMATCH"
+
+
+class BsrBf16Workload(Workload):
+    """BASELINE config 4.  The reference has no bf16: A and B are rounded to bf16 (RNE) before BOTH the oracle
+    and the kernel; fp32 accumulate on v_mfma_f32_16x16x32_bf16; C fp32."""
+    fmt = "bsr"
+    dtype = "bf16"
+
+    def __init__(self, args, matrix, n, label, block=16):
+        import torch
+        from mispmm import datasets, formats, ops, synth
+        self.args, self.n, self.label, self.matrix, self.block = args, n, label, matrix, block
+        self.csr = datasets.load_csr(matrix)
+        self.bsr = formats.csr_to_bsr(self.csr, block)
+        self.b_host = synth.dense_b(self.csr.num_cols, n)
+        self.a = ops.DeviceBSR.from_host(self.bsr)
+        self.blocks16 = ops.f32_to_bf16(self.a.data)
+        self.b16 = ops.f32_to_bf16(torch.from_numpy(self.b_host).cuda())
+        self.c = torch.empty((self.csr.num_rows, n), dtype=torch.float32, device="cuda")
+        self.a16_host = synth.bf16_round(self.bsr.data.reshape(-1)).reshape(self.bsr.data.shape)
+        self.b16_host = synth.bf16_round(self.b_host.reshape(-1)).reshape(self.b_host.shape)
+        self.flops = datasets.spmm_flops(self.csr.nnz, n)                       # useful flops (non-zeros of A)
+        self.executed_flops = 2.0 * self.bsr.num_blocks * block * block * n       # dense block products
+        self.abytes = datasets.bsr_algorithmic_bytes(self.bsr, n, elem=2, out_elem=4)
+        self.workload = (f"{matrix} BSR block {block} {self.csr.num_rows}x{self.csr.num_cols} "
+                         f"{self.bsr.num_blocks} blocks (nnz {self.csr.nnz}) x dense K={n} bf16, C fp32")
+        self.extra_config = {"block_dim": block, "blocks": int(self.bsr.num_blocks)}
+        self.has_fast = False
+
+    def step(self, stream, acc=None):
+        from mispmm import ops
+        ops.spmm_bsr_bf16(self.a, self.blocks16, self.b16, out_bf16=False, out=self.c, stream=stream)
+
+    def host_result(self):
+        return self.c.cpu().numpy()
+
+    def oracle_call(self, orc):
+        s = self.bsr
+        return lambda: orc.spmm_bsr(s.num_rows, self.block, self.block, s.block_row_ptrs, s.block_col_idxs,
+                                    self.a16_host, self.b16_host)
+
+    def oracle_threads_call(self, orc, threads):
+        return None
+
+    def check(self, orc, got, ref, acc):
+        from mispmm import synth
+        c = self.csr
+        scale = orc.spmm_csr(c.row_ptrs, c.col_idxs, np.abs(synth.bf16_round(c.data)),
+                             np.abs(self.b16_host)).astype(np.float64)
+        ok = np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+        return "within 2e-6 of sum|a||b| (bf16-rounded inputs, fp32 accumulate)" if ok else "MISMATCH"
+
+
+def make_workload(args):
+    cfg = args.config
+    if cfg == "headline":
+        m, n = args.matrix or "n4c6-b13", args.k_cols or 128
+        return CsrWorkload(args, m, n, "large_25605" if m == "n4c6-b13" else m)
+    if cfg == "2":
+        m, n = args.matrix or "delaunay_n12", args.k_cols or 128
+        return CsrWorkload(args, m, n, "medium_4096 (stand-in delaunay_n12)" if m == "delaunay_n12" else m)
+    if cfg == "3":
+        m, n = args.matrix or "n4c6-b13", args.k_cols or 256
+        return EllWorkload(args, m, n, "large_25605" if m == "n4c6-b13" else m)
+    if cfg == "4":
+        m, n = args.matrix or "ACTIVSg10K", args.k_cols or 128
+        return BsrBf16Workload(args, m, n, "large_20000" if m == "ACTIVSg10K" else m)
+    m, n = args.matrix or "n4c6-b13", args.k_cols or 512
+    return CsrWorkload(args, m, n, "large_25605" if m == "n4c6-b13" else m)
+
+
+def metric_label(w):
+    kind = {"csr": "CSR", "ell": "ELL", "bsr": f"BSR block {getattr(w, 'block', 0)}"}[w.fmt]
+    return f"SpMM GFLOP/s, {w.label} ({w.matrix}) {kind} x dense K={w.n} {'bf16' if w.dtype == 'bf16' else 'fp32'}"
+
+
+# ------------------------------------------------------------------------------------------ CPU leg
+def cpu_baseline(w, budget_s, gpu_result, acc):
+    """The oracle (a port of the reference's sequential CPU engine for this format) timed on this host with 1
+    thread on the full workload -- and, since its output is at hand, the checker of the GPU result."""
     from oracle import oracle as orc
     orc.build()
-    ref = orc.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)         # warm + checker
-    if acc == "reference":
-        parity = "bit-exact" if np.array_equal(gpu_result, ref) else "MISMATCH"
-    else:
-        scale = orc.spmm_csr(csr.row_ptrs, csr.col_idxs, np.abs(csr.data), np.abs(b)).astype(np.float64)
-        ok = np.all(np.abs(gpu_result.astype(np.float64) - ref) <= 1e-5 * scale + 1e-37)
-        parity = "within 1e-5" if ok else "MISMATCH"
+    call = w.oracle_call(orc)
+    t0 = time.perf_counter()
+    ref = call()                                                        # warm + checker
+    first = time.perf_counter() - t0
+    parity = w.check(orc, gpu_result, ref, acc)
     if parity == "MISMATCH":
         raise SystemExit("bench: GPU result does not match the oracle -- refusing to report a number")
-    times, t_end = [], time.perf_counter() + budget_s
+    times, t_end = [first], time.perf_counter() + max(0.0, budget_s - first)
     while time.perf_counter() < t_end and len(times) < 5000:
         t0 = time.perf_counter()
-        orc.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        call()
         times.append(time.perf_counter() - t0)
     best = min(times)
-    # the same engine with its row loop split over the host cores this process may use (the reference is
-    # single-threaded; this is the "host cores" column of SURVEY.md section 8(d)), a few seconds of it
+    out = {"value": round(w.flops / best / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+           "ms_per_step": round(best * 1e3, 4), "gpu_parity": parity,
+           "sample": f"the full workload ({w.workload}), best of {len(times)} runs in {budget_s:.0f} s, "
+                     f"oracle/spmm_oracle.c -O2, host has {os.cpu_count()} logical cores"}
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
-    mt = orc.spmm_csr_mt(csr.row_ptrs, csr.col_idxs, csr.data, b, threads)
-    if not np.array_equal(mt, ref):
-        raise SystemExit("bench: threaded CPU engine differs from the sequential one")
-    mt_times, t_end = [], time.perf_counter() + min(3.0, budget_s)
-    while time.perf_counter() < t_end and len(mt_times) < 5000:
+    mt_call = w.oracle_threads_call(orc, threads)
+    if mt_call is not None:
+        # the same engine with its row loop split over the host cores (the reference is single-threaded;
+        # this is the "host cores" column of SURVEY.md section 8(d))
+        if not np.array_equal(mt_call(), ref):
+            raise SystemExit("bench: threaded CPU engine differs from the sequential one")
+        mt_times, t_end = [], time.perf_counter() + min(3.0, budget_s)
+        while time.perf_counter() < t_end and len(mt_times) < 5000:
+            t0 = time.perf_counter()
+            mt_call()
+            mt_times.append(time.perf_counter() - t0)
+        mt_best = min(mt_times)
+        out["all_cores"] = {"value": round(w.flops / mt_best / 1e9, 3), "unit": "GFLOP/s", "cores": threads,
+                            "ms_per_step": round(mt_best * 1e3, 4),
+                            "note": "same engine, row loop split with OpenMP, bit-identical result"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------ timing
+class Timer:
+    def __init__(self, stream):
+        from mispmm import capi
+        self.capi, self.l = capi, capi.lib()
+        self.stream = stream
+        self.sp = ctypes.c_void_p(stream.cuda_stream)
+        self.ev0, self.ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+        capi.check(self.l.mispmm_event_create(ctypes.byref(self.ev0)))
+        capi.check(self.l.mispmm_event_create(ctypes.byref(self.ev1)))
+
+    def capture(self, fn, steps):
+        """`steps` calls of fn captured into hipGraphs of at most 1000 kernel nodes; returns the launch list."""
+        chunk = min(steps, 1000)
+        plan = [chunk] * (steps // chunk) + ([steps % chunk] if steps % chunk else [])
+        cache, graphs = {}, []
+        for size in plan:
+            if size not in cache:
+                self.capi.check(self.l.mispmm_graph_begin(self.sp))
+                for _ in range(size):
+                    fn()
+                g = ctypes.c_void_p()
+                self.capi.check(self.l.mispmm_graph_end(self.sp, ctypes.byref(g)))
+                cache[size] = g
+            graphs.append(cache[size])
+        return graphs
+
+    def _pass(self, graphs, fn, steps):
+        if graphs:
+            for g in graphs:
+                self.capi.check(self.l.mispmm_graph_launch(g, self.sp))
+        else:
+            for _ in range(steps):
+                fn()
+
+    def event_ms(self, body):
+        import torch
+        ms = ctypes.c_float()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        orc.spmm_csr_mt(csr.row_ptrs, csr.col_idxs, csr.data, b, threads)
-        mt_times.append(time.perf_counter() - t0)
-    mt_best = min(mt_times)
-    return {"value": round(2.0 * csr.nnz * b.shape[1] / best / 1e9, 3), "unit": "GFLOP/s", "cores": 1,
-            "all_cores": {"value": round(2.0 * csr.nnz * b.shape[1] / mt_best / 1e9, 3), "unit": "GFLOP/s",
-                          "cores": threads, "ms_per_step": round(mt_best * 1e3, 4),
-                          "note": "same engine, row loop split with OpenMP, bit-identical result"},
-            "kind": "port", "ms_per_step": round(best * 1e3, 4), "gpu_parity": parity,
-            "sample": f"the full workload ({csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x K={b.shape[1]}), "
-                      f"best of {len(times)} runs in {budget_s:.0f} s, oracle/spmm_oracle.c -O2, "
-                      f"host has {os.cpu_count()} logical cores"}
+        self.capi.check(self.l.mispmm_event_record(self.ev0, self.sp))
+        body()
+        self.capi.check(self.l.mispmm_event_record(self.ev1, self.sp))
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        self.capi.check(self.l.mispmm_event_elapsed_ms(self.ev0, self.ev1, ctypes.byref(ms)))
+        return ms.value, wall * 1e3
+
+    def measure(self, fn, steps, use_graph=True, timed_s=TIMED_S, precondition_s=PRECONDITION_S, rounds=ROUNDS,
+                min_nodes=MIN_GRAPH_NODES):
+        """Per-step statistics of `steps` captured calls of fn, replayed R times per round (see module docstring).
+        A graph shorter than `min_nodes` launches is captured several times over into one graph: two consecutive
+        hipGraphLaunch calls leave the GPU idle for about 7 us (measured: 20-step graphs 3.92 us per step, a
+        2000-step graph 3.57), which is launch machinery of the graph API and not part of a step."""
+        import torch
+        requested = steps
+        steps = steps * max(1, -(-min_nodes // steps)) if use_graph else steps
+        graphs = self.capture(fn, steps) if use_graph else None
+        self._pass(graphs, fn, steps)                      # graph upload / first touch, untimed
+        torch.cuda.synchronize()
+        ms1, _ = self.event_ms(lambda: self._pass(graphs, fn, steps))   # a first estimate of one pass
+        est = max(ms1 * 1e-3, 1e-7)
+        t_end = time.perf_counter() + precondition_s       # precondition: clocks and caches in steady state
+        n_pre = 0
+        while time.perf_counter() < t_end or n_pre < 2:
+            for _ in range(max(1, int(0.005 / est))):
+                self._pass(graphs, fn, steps)
+            torch.cuda.synchronize()
+            n_pre += 1
+        replays = max(1, int(np.ceil(timed_s / est)))
+        per_step_us, wall_ms = [], 0.0
+        for _ in range(rounds):
+            ms, wall = self.event_ms(lambda: [self._pass(graphs, fn, steps) for _ in range(replays)])
+            per_step_us.append(ms * 1e3 / (steps * replays))
+            wall_ms += wall
+        per_step_us = np.array(per_step_us)
+        if graphs:
+            for g in set(g.value for g in graphs):
+                self.capi.check(self.l.mispmm_graph_destroy(ctypes.c_void_p(g)))
+        return {"median_us": float(np.median(per_step_us)), "min_us": float(per_step_us.min()),
+                "max_us": float(per_step_us.max()), "replays": replays * (steps // requested), "rounds": rounds,
+                "graph_nodes": steps if use_graph else 0,
+                "wall_us": wall_ms * 1e3 / (steps * replays * rounds)}
 
 
-def event_pair(l):
-    a, b = ctypes.c_void_p(), ctypes.c_void_p()
-    from mispmm import capi
-    capi.check(l.mispmm_event_create(ctypes.byref(a)))
-    capi.check(l.mispmm_event_create(ctypes.byref(b)))
-    return a, b
+def load_traffic(key, kernel_tag):
+    """L2<->fabric bytes per launch from the committed rocprofv3 PMC passes -- only when the entry was taken on
+    the kernel that just ran (PMC counters cannot be read from inside this process)."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            entry = json.load(f).get(key)
+    except (OSError, ValueError):
+        return None, "no committed PMC entry"
+    if not entry:
+        return None, "no committed PMC entry for this workload"
+    if entry.get("kernel_tag") != kernel_tag:
+        return None, f"committed PMC entry is for kernel {entry.get('kernel_tag')!r}, this run used {kernel_tag!r}"
+    return entry["total_bytes"], entry.get("source", TRAFFIC_JSON)
 
 
 def run_single(args):
     import torch
-    from mispmm import capi, datasets, ops, synth
-    l = capi.lib()
+    from mispmm import capi
+    capi.lib()
     torch.cuda.set_device(0)
-    csr = datasets.load_csr(args.matrix)
-    n = args.k_cols
-    b_host = synth.dense_b(csr.num_cols, n)
-    a = ops.DeviceCSR.from_host(csr)
-    b = torch.from_numpy(b_host).cuda()
-    c = torch.empty((csr.num_rows, n), dtype=torch.float32, device="cuda")
+    w = make_workload(args)
     stream = torch.cuda.Stream()
-    sp = ctypes.c_void_p(stream.cuda_stream)
+    timer = Timer(stream)
 
     def step():
-        ops.spmm_csr(a, b, out=c, kernel=args.kernel, acc=args.acc, stream=stream)
+        w.step(stream)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    kernel_tag = capi.last_kernel()
 
-    graphs = []
-    if args.launch == "graph":
-        chunk = min(args.steps, 1000)
-        plan = [chunk] * (args.steps // chunk) + ([args.steps % chunk] if args.steps % chunk else [])
-        cache = {}
-        for size in plan:
-            if size not in cache:
-                capi.check(l.mispmm_graph_begin(sp))
-                for _ in range(size):
-                    step()
-                g = ctypes.c_void_p()
-                capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
-                cache[size] = g
-            graphs.append(cache[size])
-        for g in set(g.value for g in graphs):   # one untimed replay per graph (upload)
-            capi.check(l.mispmm_graph_launch(ctypes.c_void_p(g), sp))
-        torch.cuda.synchronize()
+    stat = timer.measure(step, args.steps, use_graph=args.launch == "graph")
+    step()                                # leave the timed mode's result in C for the parity check
+    torch.cuda.synchronize()
+    got = w.host_result()
 
-    ev0, ev1 = event_pair(l)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    capi.check(l.mispmm_event_record(ev0, sp))
-    if graphs:
-        for g in graphs:
-            capi.check(l.mispmm_graph_launch(g, sp))
-    else:
-        for _ in range(args.steps):
-            step()
-    capi.check(l.mispmm_event_record(ev1, sp))
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms = ctypes.c_float()
-    capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)))
-
-    # the other accumulate mode, same launches, for the record (never `value`)
-    other = "fast" if args.acc == "reference" else "reference"
-    n_other = min(args.steps, 500)
-    capi.check(l.mispmm_graph_begin(sp))
-    for _ in range(n_other):
-        ops.spmm_csr(a, b, out=c, kernel=args.kernel, acc=other, stream=stream)
-    g_other = ctypes.c_void_p()
-    capi.check(l.mispmm_graph_end(sp, ctypes.byref(g_other)))
-    capi.check(l.mispmm_graph_launch(g_other, sp))
-    torch.cuda.synchronize()
-    capi.check(l.mispmm_event_record(ev0, sp))
-    capi.check(l.mispmm_graph_launch(g_other, sp))
-    capi.check(l.mispmm_event_record(ev1, sp))
-    torch.cuda.synchronize()
-    ms_other = ctypes.c_float()
-    capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms_other)))
-    other_us = ms_other.value * 1e3 / n_other
-    step()                      # leave the timed mode's result in C for the parity check
-    torch.cuda.synchronize()
-
-    # cold single shot (SURVEY.md 8(d) asks for it next to the steady-state figure): 1 GiB is written first so that
-    # neither the L2s nor the 256 MiB Infinity Cache hold A, B or C; median of 5; HIP events around ONE eager launch
-    # (an empty event pair costs a few microseconds itself, reported beside it)
-    cold, empty = [], []
-    flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
-    with torch.cuda.stream(stream):
-        for _ in range(5):
-            flush.fill_(1.0)
-            capi.check(l.mispmm_event_record(ev0, sp))
-            step()
-            capi.check(l.mispmm_event_record(ev1, sp))
-            stream.synchronize()
-            capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms_other)))
-            cold.append(ms_other.value * 1e3)
-            capi.check(l.mispmm_event_record(ev0, sp))
-            capi.check(l.mispmm_event_record(ev1, sp))
-            stream.synchronize()
-            capi.check(l.mispmm_event_elapsed_ms(ev0, ev1, ctypes.byref(ms_other)))
-            empty.append(ms_other.value * 1e3)
-    del flush
-    cold_us, empty_us = sorted(cold)[2], sorted(empty)[2]
-
-    flops = datasets.spmm_flops(csr.nnz, n)
-    abytes = datasets.csr_algorithmic_bytes(csr, n)
-    traffic = None     # PMC counters cannot be read from inside this process: committed rocprofv3 figure
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as f:
-            entry = json.load(f).get(f"{args.matrix}/{n}")
-        if entry and args.kernel in (0, 5):
-            traffic = entry["total_bytes"]
-    except OSError:
-        pass
-    launch_s = ms.value * 1e-3 / args.steps
-    achieved = abytes / launch_s / 1e9
+    launch_us = stat["median_us"]
+    achieved = w.abytes / (launch_us * 1e-6) / 1e9
+    traffic, traffic_src = load_traffic(f"{args.config}:{w.matrix}/{w.n}/{args.acc}", kernel_tag)
     info = capi.device_info(0)
     out = {
-        "metric": "SpMM GFLOP/s, large_25605 (n4c6-b13) CSR x dense K=%d fp32" % n,
-        "value": round(flops * args.steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 6),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": "SuiteSparse n4c6-b13 (reference data/large_25605) x seeded synthetic B",
-        "config": {"workload": f"{args.matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
-                   "kernel": args.kernel, "acc_mode": args.acc, "launch": args.launch, "device": info["name"],
-                   "uniform_row_hint": a.uniform_row_nnz if args.kernel in (0, 5) else 0},
-        "achieved_hbm_GBps": round(abytes * args.steps / wall / 1e9, 1),
-        "other_acc_mode": {"acc_mode": other, "launch_us": round(other_us, 3),
-                           "roofline_frac": round(abytes / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                           "note": "reference = the reference engine's fp64 accumulate (bit-exact); fast = fp32 fma chain (<= 1e-5)"},
-        "cold_single_shot": {"launch_us": round(cold_us, 2), "empty_event_pair_us": round(empty_us, 2),
-                             "note": "one eager launch after a 1 GiB cache flush, HIP events, median of 5 (not the metric)"},
+        "metric": metric_label(w),
+        "value": round(w.flops / (launch_us * 1e-6) / 1e9, 2), "unit": "GFLOP/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(launch_us * 1e-3, 6),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": w.dtype,
+        "data": f"SuiteSparse {w.matrix} (reference data/{w.label.split(' ')[0]}) x seeded synthetic B",
+        "config": {"workload": w.workload, "baseline_config": args.config, "kernel": args.kernel,
+                   "kernel_tag": kernel_tag, "acc_mode": args.acc if w.has_fast else "fp32 accumulate (MFMA)",
+                   "launch": args.launch, "device": info["name"], **w.extra_config},
+        "timing": {"method": f"the {args.steps} steps captured into hipGraphs of {stat['graph_nodes']} launches, the steps "
+                             f"replayed {stat['replays']}x per round inside one HIP-event pair, {stat['rounds']} rounds, after "
+                             f">= {int(PRECONDITION_S * 1e3)} ms of untimed replays; value / ms_per_step / roofline use the median round",
+                   "replays": stat["replays"], "rounds": stat["rounds"], "median_us": round(stat["median_us"], 4),
+                   "min_us": round(stat["min_us"], 4), "max_us": round(stat["max_us"], 4),
+                   "host_wall_us_per_step": round(stat["wall_us"], 4)},
+        "achieved_hbm_GBps": round(achieved, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": abytes, "launch_us": round(launch_s * 1e6, 3),
-                     "note": "launch_us = HIP-event time over the timed region / steps (includes inter-kernel gaps); "
-                             "traffic = L2<->fabric bytes per launch from rocprofv3 PMC (profiles/r1/traffic.json)"},
+                     "algorithmic_bytes_per_launch": w.abytes, "launch_us": round(launch_us, 4),
+                     "frac_at_min": round(w.abytes / (stat["min_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "launch_us = HIP-event time of the timed region / launches in it (inter-kernel gaps "
+                             "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src)},
     }
+    if w.fmt == "bsr":
+        ex = w.executed_flops / (launch_us * 1e-6) / 1e12
+        out["mfma"] = {"executed_TFLOPs": round(ex, 2), "dense_bf16_peak_frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4),
+                       "note": "dense block products on a 1.6 % filled BSR; `value` counts the useful flops (2*nnz*K)"}
+    if not args.no_extras:
+        if args.launch == "graph" and args.steps < MIN_GRAPH_NODES:
+            g = timer.measure(step, args.steps, rounds=3, precondition_s=0.01, min_nodes=1)
+            out["timing"]["graph_of_exactly_steps_us"] = round(g["median_us"], 4)
+            out["timing"]["graph_of_exactly_steps_note"] = (
+                f"the same steps as a {args.steps}-launch graph replayed back to back: the difference to median_us is the "
+                "idle time between two hipGraphLaunch calls, spread over the steps of one graph")
+        if w.has_fast:
+            other = "fast" if args.acc == "reference" else "reference"
+            o = timer.measure(lambda: w.step(stream, acc=other), min(args.steps, 500), rounds=3, precondition_s=0.01)
+            out["other_acc_mode"] = {
+                "acc_mode": other, "launch_us": round(o["median_us"], 4),
+                "roofline_frac": round(w.abytes / (o["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "reference = the reference engine's accumulate (bit-exact); fast = fp32 fma chain (<= 1e-5)"}
+        # cold single shot (SURVEY.md 8(d) asks for it next to the steady-state figure): 1 GiB is written first so
+        # that neither the L2s nor the 256 MiB Infinity Cache hold A, B or C; median of 5; HIP events around ONE
+        # eager launch (an empty event pair costs a few microseconds itself, reported beside it)
+        cold, empty = [], []
+        flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        ms = ctypes.c_float()
+        l = timer.l
+        with torch.cuda.stream(stream):
+            for _ in range(5):
+                flush.fill_(1.0)
+                capi.check(l.mispmm_event_record(timer.ev0, timer.sp))
+                step()
+                capi.check(l.mispmm_event_record(timer.ev1, timer.sp))
+                stream.synchronize()
+                capi.check(l.mispmm_event_elapsed_ms(timer.ev0, timer.ev1, ctypes.byref(ms)))
+                cold.append(ms.value * 1e3)
+                capi.check(l.mispmm_event_record(timer.ev0, timer.sp))
+                capi.check(l.mispmm_event_record(timer.ev1, timer.sp))
+                stream.synchronize()
+                capi.check(l.mispmm_event_elapsed_ms(timer.ev0, timer.ev1, ctypes.byref(ms)))
+                empty.append(ms.value * 1e3)
+        del flush
+        out["cold_single_shot"] = {"launch_us": round(sorted(cold)[2], 2), "empty_event_pair_us": round(sorted(empty)[2], 2),
+                                   "note": "one eager launch after a 1 GiB cache flush, HIP events, median of 5 (not the metric)"}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(csr, b_host, args.cpu_seconds, c.cpu().numpy(), args.acc)
-    print(json.dumps(out))
+        out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, got, args.acc)
+    print(json.dumps(out), flush=True)
 
 
+# ------------------------------------------------------------------------------------------ N > 1
 def run_multi(args):
     import torch
     import torch.distributed as dist
@@ -250,79 +494,141 @@ def run_multi(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    ndev = torch.cuda.device_count()
+    shared_gpu = os.environ.get("MISPMM_SHARE_GPU") == "1"        # rehearsal: several ranks on one card (gloo + IPC)
+    dev_index = 0 if shared_gpu else local % max(1, ndev)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    if shared_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     capi.lib()
-    csr = datasets.load_csr(args.matrix)
-    n = args.k_cols
-    job = mdist.ShardedCsrSpmm(csr, n, device=torch.device("cuda", local), kernel=args.kernel, acc=args.acc,
-                               bucket=args.bucket)
+    cfg_matrix = args.matrix or "n4c6-b13"
+    n = args.k_cols or (512 if args.config == "5" else 128)
+    csr = datasets.load_csr(cfg_matrix)
+    modes = ["allgather", "peer"] if args.exchange == "both" else [args.exchange]
+    if shared_gpu:
+        modes = [m for m in modes if m == "peer"] or ["peer"]
     b_host = synth.dense_b(csr.num_cols, n) if rank == 0 else None
-    job.broadcast_b(b_host)                      # one-time, outside the timed region
-    job.run(args.warmup)
-    job.finish()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    job.run(args.steps)
-    job.finish()
-    torch.cuda.synchronize()
-    dist.barrier()
-    wall = time.perf_counter() - t0
-    # the same steps with C left row-sharded (no collective): the kernel-only figure
-    dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    job.run(args.steps, gather=False)
-    job.finish(gather=False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    compute_s = time.perf_counter() - t1
-    t = torch.tensor([wall, compute_s], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, compute_s = float(t[0]), float(t[1])
-    # sharded + gathered C must equal the unsharded single-GPU product bit for bit (row independence)
-    ok = True
-    if rank == 0:
-        from mispmm import ops
-        whole = ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=job.device), job.b, kernel=args.kernel, acc=args.acc)
+    flops = datasets.spmm_flops(csr.nnz, n)
+    abytes = datasets.csr_algorithmic_bytes(csr, n)
+    results, whole = {}, None
+    for mode in modes:
+        try:
+            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=args.bucket,
+                                       exchange=mode)
+        except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
+            results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
+            job = None
+        # every rank must agree on whether the mode is usable
+        flag = torch.tensor([1.0 if job is not None else 0.0], device="cpu" if shared_gpu else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) == 0.0:
+            if job is not None:
+                job.close()
+                results[mode] = {"unavailable": "another rank could not set the exchange up"}
+            continue
+        job.broadcast_b(b_host)                      # one-time, outside the timed region
+        job.run(args.warmup)
+        job.finish()
+        dist.barrier()
         torch.cuda.synchronize()
-        ok = bool(torch.equal(whole, job.gathered_c()))
+        t0 = time.perf_counter()
+        job.run(args.steps)
+        job.finish()
+        torch.cuda.synchronize()
+        dist.barrier()
+        wall = time.perf_counter() - t0
+        # the same steps with C left row-sharded (no exchange): the kernel-only figure
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        job.run(args.steps, gather=False)
+        job.finish(gather=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        compute_s = time.perf_counter() - t1
+        t = torch.tensor([wall, compute_s], dtype=torch.float64, device="cpu" if shared_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, compute_s = float(t[0]), float(t[1])
+        # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
+        job.run(1)
+        job.finish()
+        from mispmm import ops
+        if whole is None:
+            whole = ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=device), job.b, kernel=args.kernel, acc=args.acc)
+            torch.cuda.synchronize()
+        ok = torch.tensor([1.0 if torch.equal(whole, job.gathered_c()) else 0.0], device="cpu" if shared_gpu else device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok[0]) == 0.0:
+            raise SystemExit(f"bench: exchanged C ({mode}) differs from the unsharded product -- refusing to report a number")
+        results[mode] = {"value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
+                         "kernel_only_value": round(flops * args.steps / compute_s / 1e9, 2),
+                         "kernel_only_ms_per_step": round(compute_s * 1e3 / args.steps, 6)}
+        job.close()
     if rank == 0:
-        if not ok:
-            raise SystemExit("bench: gathered C differs from the unsharded product -- refusing to report a number")
-        flops = datasets.spmm_flops(csr.nnz, n)
-        abytes = datasets.csr_algorithmic_bytes(csr, n)
+        usable = {m: r for m, r in results.items() if "value" in r}
+        if not usable:
+            raise SystemExit(f"bench: no exchange mode could run: {results}")
+        best = max(usable, key=lambda m: usable[m]["value"])
+        r = usable[best]
+        label = "large_25605" if cfg_matrix == "n4c6-b13" else cfg_matrix
         out = {
-            "metric": "SpMM GFLOP/s, large_25605 (n4c6-b13) CSR x dense K=%d fp32" % n,
-            "value": round(flops * args.steps / wall / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 6),
+            "metric": f"SpMM GFLOP/s, {label} ({cfg_matrix}) CSR x dense K={n} fp32",
+            "value": r["value"], "unit": "GFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-            "data": "SuiteSparse n4c6-b13 (reference data/large_25605) x seeded synthetic B",
-            "config": {"workload": f"{args.matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
-                       "parallelism": f"row-sharded x{world}, B replicated, C slabs all-gathered (RCCL) every "
-                                      f"{args.bucket} steps", "kernel": args.kernel, "acc_mode": args.acc,
-                       "check": "gathered C == unsharded single-GPU C (bitwise)"},
-            "achieved_hbm_GBps": round(abytes * args.steps / wall / 1e9, 1),
-            "kernel_only": {"value": round(flops * args.steps / compute_s / 1e9, 2), "unit": "GFLOP/s",
-                            "ms_per_step": round(compute_s * 1e3 / args.steps, 6),
-                            "note": "the same steps re-run with C left row-sharded (no collective), max over ranks"},
-            "roofline": {"bound": "hbm", "achieved": round(abytes * args.steps / compute_s / 1e9, 1),
+            "data": f"SuiteSparse {cfg_matrix} (reference data/{label}) x seeded synthetic B",
+            "config": {"workload": f"{cfg_matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
+                       "parallelism": f"row-sharded x{world}, B replicated, C slabs exchanged every {args.bucket} steps "
+                                      f"({best}: " + ("RCCL all_gather_into_tensor" if best == "allgather" else
+                                                      "direct copies into IPC-mapped peer buffers over xGMI") + ")",
+                       "kernel": args.kernel, "acc_mode": args.acc,
+                       "check": "exchanged C == unsharded single-GPU C (bitwise) on every rank"},
+            "achieved_hbm_GBps": round(abytes / (r["ms_per_step"] * 1e-3) / 1e9, 1),
+            "exchange_modes": results,
+            "kernel_only": {"value": r["kernel_only_value"], "unit": "GFLOP/s", "ms_per_step": r["kernel_only_ms_per_step"],
+                            "note": "the same steps re-run with C left row-sharded (no exchange), max over ranks"},
+            "roofline": {"bound": "hbm", "achieved": round(abytes / (r["kernel_only_ms_per_step"] * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": round(abytes * args.steps / compute_s / 1e9 / (HBM_PEAK_GBS * world), 4),
-                         "traffic": None},
+                         "frac": round(abytes / (r["kernel_only_ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "traffic": None, "note": "kernel-only time against the N-GPU aggregate HBM peak"},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly: start one child per rank (fresh processes; this parent never
+    touches the GPU), relay rank 0's JSON line, exit with the worst child status."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MISPMM_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    force = os.environ.get("MISPMM_FORCE_DIST") == "1"    # rehearse the RCCL path with a single rank
-    if args.gpus > 1 or world > 1 or force:
-        if world == 1 and not force:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    force = os.environ.get("MISPMM_FORCE_DIST") == "1"    # rehearse the distributed path with a single rank
+    if args.gpus > 1 and world == 1 and not force:
+        spawn_ranks(args)
+    elif args.gpus > 1 or world > 1 or force:
         run_multi(args)
     else:
         run_single(args)

@@ -15,6 +15,9 @@ constexpr int kWave = 64;  // CDNA wavefront width; hard-coded on purpose
 // thread-local detail string behind mispmm_last_error()
 void set_error(const char *fmt, ...);
 int fail(int status, const char *fmt, ...);
+// thread-local tag of the device kernel the last compute call enqueued (mispmm_last_kernel(): lets a
+// measurement tie a PMC figure to the kernel that actually ran)
+void note_kernel(const char *fmt, ...);
 
 inline hipStream_t as_stream(mispmm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

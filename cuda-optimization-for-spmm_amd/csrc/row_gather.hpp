@@ -21,6 +21,7 @@ namespace mispmm {
 #ifdef MISPMM_STAMPS
 // Diagnostic build only (tools/stamp_headline.py): every wave leaves s_memrealtime stamps (100 MHz) in a side buffer.
 static __device__ unsigned long long *mispmm_stamp_buf = nullptr;
+constexpr uint32_t kStampLaunches = 32;  // the side buffer keeps the records of the last 32 launches (8 x uint64 per wave)
 #endif
 
 struct CsrRows {
@@ -60,7 +61,11 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     // with a kernarg fetch in front of the row-pointer fetch
     uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
-    const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc) {
+    const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc
+#ifdef MISPMM_STAMPS
+    , uint32_t stamp_launch  // which of the last kStampLaunches launches this is: each keeps its own stamp records
+#endif
+    ) {
 #ifdef MISPMM_STAMPS
     unsigned long long stamp[5];
     stamp[0] = wall_clock64();
@@ -72,8 +77,8 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t p = xcd & ((1u << log2p) - 1u), q = xcd >> log2p;
     const uint32_t row = (p * rb_chunk + slot) * GROUPS + threadIdx.x / G;
-    const uint32_t col0 = q * cols_per_part + blockIdx.y * (G * VEC) + lane * VEC;
     const bool row_ok = row < M;
+    const uint32_t col0 = q * cols_per_part + blockIdx.y * (G * VEC) + lane * VEC;
     const bool col_ok = col0 < min(N, (q + 1) * cols_per_part);
     size_t row_base = 0;
     uint32_t row_len = 0;
@@ -285,15 +290,26 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[4] = wall_clock64();
     if (mispmm_stamp_buf && (threadIdx.x & 63) == 0) {
-        unsigned long long *o = mispmm_stamp_buf +
-            ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (BLOCK / 64) + (threadIdx.x >> 6)) * 8;
+        const uint32_t wpb = blockDim.x / 64;
+        const size_t waves_per_launch = static_cast<size_t>(gridDim.x) * gridDim.y * wpb;
+        unsigned long long *o = mispmm_stamp_buf + (stamp_launch * waves_per_launch +
+            (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * wpb + (threadIdx.x >> 6)) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) o[i] = stamp[i];
+        // where the wave ran: HW_REG_HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and HW_REG_XCC_ID (id 20)
+        o[5] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 4));
+        o[6] = static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((31 << 11) | 20));
     }
 #endif
 }
 
 // ---- host side -------------------------------------------------------------------------------
+template <class Rows> constexpr const char *rows_tag() {
+    if constexpr (std::is_same_v<Rows, CsrRows>) return "csr";
+    else if constexpr (std::is_same_v<Rows, UniformRows>) return "uniform";
+    else return "ell";
+}
+
 struct RowGatherArgs {
     hipStream_t stream;
     uint32_t M, K;
@@ -365,13 +381,23 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
+    note_kernel("row_gather<G%d,V%d,%s,%s,B%d,U%d,%s,S%d> xcd %ux%u", G, VEC, acc_tag<Acc>(), rows_tag<Rows>(), BLOCK, UMAX,
+                ROLL ? "roll" : "batch", SLOTS, 1u << t.log2p, t.q);
+#ifdef MISPMM_STAMPS
+    static uint32_t stamp_counter = 0;
+    const uint32_t stamp_launch = stamp_counter++ % kStampLaunches;
+#define MISPMM_STAMP_ARG , stamp_launch
+#else
+#define MISPMM_STAMP_ARG
+#endif
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
-                           static_cast<uint32_t>(c_bytes), a.ldc);
+                           static_cast<uint32_t>(c_bytes), a.ldc MISPMM_STAMP_ARG);
     else
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
-                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc);
+                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc MISPMM_STAMP_ARG);
+#undef MISPMM_STAMP_ARG
 }
 
 template <int G, int VEC, class Acc, class Rows>

@@ -26,6 +26,15 @@ int fail(int status, const char *fmt, ...) {
     return status;
 }
 
+static thread_local char g_last_kernel[256] = "";
+
+void note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+
 XcdGrid xcd_grid(uint32_t nblk) {
     // MISPMM_XCD_REMAP=0 disables the renumbering (A/B measurements only)
     static const bool enabled = [] {
@@ -58,6 +67,8 @@ const char *mispmm_status_string(int status) {
 }
 
 const char *mispmm_last_error(void) { return g_last_error; }
+
+const char *mispmm_last_kernel(void) { return g_last_kernel; }
 
 int mispmm_device_count(int *count) {
     if (!count) return fail(MISPMM_ERR_INVALID_ARG, "count is null");

@@ -582,6 +582,7 @@ static void launch_valu(const BsrArgs &a) {
     const uint32_t M = a.Mb * a.bR;
     dim3 grid(ceil_div(M, 256 / G), ceil_div(a.N, G * VEC));
     const uint64_t bytes = static_cast<uint64_t>(a.K) * a.ldb * 4u;
+    note_kernel("bsr_valu<G%d,V%d,%s>", G, VEC, acc_tag<Acc>());
     if (bytes > 0x7FFFFFFFull)
         hipLaunchKernelGGL((bsr_valu<G, VEC, Acc, true>), grid, dim3(256), 0, a.stream, M, a.bR, a.bC, a.ptrs, a.idxs,
                            a.blocks, a.B, 0u, a.N, a.ldb, a.C, a.ldc);
@@ -605,6 +606,7 @@ static void launch_rowblock(const BsrArgs &a) {
     constexpr int RS = BD < 8 ? BD : 8;
     const uint32_t nCT = ceil_div(a.N, 64u * VEC);
     const XcdGrid xg = xcd_grid(ceil_div(a.Mb * nCT * (BD / RS), 4u));
+    note_kernel("bsr_rowblock<BD%d,RS%d,V%d,%s>", BD, RS, VEC, acc_tag<Acc>());
     hipLaunchKernelGGL((bsr_rowblock<BD, RS, VEC, Acc>), dim3(xg.grid), dim3(256), 0, a.stream, a.Mb, nCT, a.ptrs, a.idxs,
                        a.blocks, a.B, static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u), a.N, a.ldb, a.C, a.ldc,
                        xg.chunk);
@@ -669,6 +671,7 @@ extern "C" int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uin
     if (kernel == 2) {
         const uint32_t nST = ceil_div(N, 64u);
         const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, super-tile)
+        note_kernel("bsr_mfma_f32");
         hipLaunchKernelGGL(bsr_mfma_f32, dim3(xg.grid), dim3(256), 0, st, numBlockRows, nST, blockRowPtrs, blockColIdxs,
                            blocks, B, static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u), N, ldb, C, ldc, xg.chunk);
     } else {
@@ -716,6 +719,7 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
         }                                                                                        \
     } while (0)
     // (8 waves per workgroup -- WAVES = 8, half the iterations per wave -- was measured slower: 13.2 vs 11.6 us)
+    note_kernel("bsr_mfma_bf16%s<T%d,%s>", bR == 32 ? "_b32" : "", wide ? 8 : 4, c_bf16 ? "c16" : "c32");
     if (bR == 16 && !bsr_pipe && wide) {
         if (c_bf16) hipLaunchKernelGGL((bsr_mfma_bf16<8, true, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);
         else hipLaunchKernelGGL((bsr_mfma_bf16<8, false, false>), grid, dim3(256), 0, as_stream(stream), numBlockRows, nST, blockRowPtrs, blockColIdxs, blocks, B, b_bytes, N, ldb, C, ldc, xg.chunk);

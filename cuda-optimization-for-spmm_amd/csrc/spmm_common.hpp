@@ -160,6 +160,12 @@ struct AccFast {
     static __device__ __forceinline__ float finish(T acc) { return acc; }
 };
 
+template <class Acc> constexpr const char *acc_tag() {
+    if constexpr (std::is_same_v<Acc, AccRefWide>) return "ref64";
+    else if constexpr (std::is_same_v<Acc, AccRefF32>) return "ref32";
+    else return "fast";
+}
+
 // Widest vector width usable for row-major dense operands B (ldb) and C (ldc) with N columns.
 inline int pick_vec(const float *B, uint32_t ldb, const float *C, uint32_t ldc, uint32_t N) {
     static const int cap = [] { const char *e = getenv("MISPMM_VEC"); return e ? atoi(e) : 4; }();  // measurement aid

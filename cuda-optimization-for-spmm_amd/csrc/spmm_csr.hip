@@ -477,6 +477,7 @@ static void launch_grouped(const CsrArgs &a, int kernel, bool wide) {
     const XcdGrid xg = xcd_grid(ceil_div(a.M, 256 / G));
     dim3 grid(xg.grid, ceil_div(a.N, G * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    note_kernel("%s<G%d,V%d,%s>", wide ? "csr_wide" : kernel == 1 ? "csr_k1" : "csr_k2", G, VEC, acc_tag<Acc>());
     if (wide)
         hipLaunchKernelGGL((csr_wide<G, VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals,
                            a.B, a.N, a.ldb, a.C, a.ldc, xg.chunk);
@@ -503,6 +504,7 @@ static void launch_wave(const CsrArgs &a) {
     const XcdGrid xg = xcd_grid(ceil_div(a.M, 4 * ROWS));
     dim3 grid(xg.grid, ceil_div(a.N, 64 * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    note_kernel("csr_k3<V%d,R%d,%s>", VEC, ROWS, acc_tag<Acc>());
     hipLaunchKernelGGL((csr_k3<VEC, ROWS, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }
@@ -512,6 +514,7 @@ static void launch_wave_deep(const CsrArgs &a) {
     const XcdGrid xg = xcd_grid(ceil_div(a.M, 4u));
     dim3 grid(xg.grid, ceil_div(a.N, 64 * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    note_kernel("csr_wave_deep<V%d,%s>", VEC, acc_tag<Acc>());
     hipLaunchKernelGGL((csr_wave_deep<VEC, Acc>), grid, dim3(256), 0, a.stream, a.M, a.rowPtrs, a.colIdxs, a.vals, a.B,
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }

@@ -25,6 +25,7 @@ SIGNATURES = {
     "mispmm_version": (_i, []),
     "mispmm_status_string": (_c.c_char_p, [_i]),
     "mispmm_last_error": (_c.c_char_p, []),
+    "mispmm_last_kernel": (_c.c_char_p, []),
     "mispmm_device_count": (_i, [_c.POINTER(_i)]),
     "mispmm_set_device": (_i, [_i]),
     "mispmm_get_device": (_i, [_c.POINTER(_i)]),
@@ -107,3 +108,8 @@ def device_info(ordinal=0):
     cus, mem = _i(0), _sz(0)
     check(lib().mispmm_device_info(ordinal, name, ctypes.byref(cus), ctypes.byref(mem)))
     return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": mem.value}
+
+
+def last_kernel():
+    """Tag of the device kernel the calling thread's last compute call enqueued."""
+    return lib().mispmm_last_kernel().decode()

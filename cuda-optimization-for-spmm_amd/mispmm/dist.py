@@ -32,7 +32,12 @@ def csr_row_slice(csr, r0, r1):
 
 
 class ShardedCsrSpmm:
-    def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None):
+    def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather"):
+        if exchange not in ("allgather", "peer"):
+            raise ValueError(f"unknown exchange mode {exchange!r}")
+        if exchange == "peer":
+            raise NotImplementedError("peer exchange: see mispmm/dist.py (IPC-mapped peer buffers)")
+        self.exchange = exchange
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = torch.device(device)
         self.on_gpu = self.device.type == "cuda"

@@ -74,6 +74,10 @@ enum mispmm_acc_mode { MISPMM_ACC_REFERENCE = 0, MISPMM_ACC_FAST = 1 };
 int mispmm_version(void);
 const char *mispmm_status_string(int status);
 const char *mispmm_last_error(void);
+/* Tag of the device kernel (template instance + XCD tiling) the calling thread's last compute call
+ * enqueued, e.g. "row_gather<G16,V4,ref64,uniform,B128,U8,roll,S14> xcd 4x2".  Diagnostic: lets a
+ * measurement tie a rocprofv3 counter figure to the kernel that actually ran. */
+const char *mispmm_last_kernel(void);
 
 /* replaces cudaSetDevice(7) (src/main.cu:176) */
 int mispmm_device_count(int *count);
