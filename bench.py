@@ -492,7 +492,11 @@ def run_multi(args):
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
+    if "MASTER_PORT" not in os.environ:                      # a lone rank rehearsing the path: any free port
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
     shared_gpu = os.environ.get("MISPMM_SHARE_GPU") == "1"        # rehearsal: several ranks on one card (gloo + IPC)

@@ -64,3 +64,32 @@ extern "C" int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs
     bounds_out_host[parts] = M;
     return MISPMM_OK;
 }
+
+extern "C" int mispmm_coo_sort_by_row_host(uint32_t M, uint32_t nnz, const uint32_t *rowIdxs_host,
+                                           const uint32_t *colIdxs_host, const float *vals_host,
+                                           uint32_t *rowIdxs_out_host, uint32_t *colIdxs_out_host,
+                                           float *vals_out_host, int *was_sorted) {
+    if (nnz != 0 && (!rowIdxs_host || !colIdxs_host || !vals_host))
+        return fail(MISPMM_ERR_INVALID_ARG, "coo sort: null input");
+    bool sorted = true;
+    for (uint32_t i = 0; i < nnz; ++i) {
+        if (rowIdxs_host[i] >= M) return fail(MISPMM_ERR_INVALID_ARG, "coo sort: row index %u out of range", rowIdxs_host[i]);
+        if (i && rowIdxs_host[i] < rowIdxs_host[i - 1]) sorted = false;
+    }
+    if (was_sorted) *was_sorted = sorted ? 1 : 0;
+    if (!rowIdxs_out_host && !colIdxs_out_host && !vals_out_host) return MISPMM_OK;  // query only
+    if (!rowIdxs_out_host || !colIdxs_out_host || !vals_out_host)
+        return fail(MISPMM_ERR_INVALID_ARG, "coo sort: an output is null");
+    // counting sort by row: stable, so every row keeps its entries in storage order -- the order in which
+    // the reference's spmmCOOCpu adds them into that row of C (spmm_coo.cpp:16-24)
+    std::vector<uint32_t> start(static_cast<size_t>(M) + 1, 0);
+    for (uint32_t i = 0; i < nnz; ++i) ++start[rowIdxs_host[i] + 1];
+    for (uint32_t r = 0; r < M; ++r) start[r + 1] += start[r];
+    for (uint32_t i = 0; i < nnz; ++i) {
+        const uint32_t o = start[rowIdxs_host[i]]++;
+        rowIdxs_out_host[o] = rowIdxs_host[i];
+        colIdxs_out_host[o] = colIdxs_host[i];
+        vals_out_host[o] = vals_host[i];
+    }
+    return MISPMM_OK;
+}

@@ -1,0 +1,226 @@
+// Row-sharded CSR SpMM over the GPUs of one node, single process: the multi-GPU slice of the C ABI.
+//
+// New capability -- the reference pins one device (cudaSetDevice(7), /root/reference/src/main.cu:176) and has
+// no exchange step of any kind.  Rows of A (hence rows of C) are independent, so device d owns the contiguous
+// row range [rowBounds[d], rowBounds[d + 1]) (cut by mispmm_shard_rows_by_nnz_host), holds a replica of B and
+// runs the single-GPU kernel on its slice; the only exchange is the gather of the C row slabs:
+//   MISPMM_GATHER_TO_FIRST   every device copies its slab into device 0's C          (peer copies over xGMI)
+//   MISPMM_GATHER_ALL_PEER   every device copies its slab into every other device's C (all-gather by peer copies)
+//   MISPMM_GATHER_ALL_RCCL   grouped in-place ncclBroadcast of each slab from its owner (all-gather-v over RCCL)
+// Everything is enqueued on the caller's per-device streams; nothing here synchronises or allocates.
+// librccl.so is loaded on first use of mispmm_comm_create, so single-GPU users never pay for it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <vector>
+
+#include "mispmm_internal.hpp"
+
+namespace mispmm {
+
+// one launch copies a slab to up to 16 destinations: blockIdx.y picks the destination, 16 bytes per lane,
+// grid-stride over the slab.  Destinations may be peer memory (IPC-mapped or peer-enabled): plain stores.
+struct ScatterDsts {
+    void *p[16];
+};
+
+__global__ __launch_bounds__(256) void slab_scatter_kernel(const uint4 *__restrict__ src, size_t n16, ScatterDsts d) {
+    uint4 *__restrict__ dst = static_cast<uint4 *>(d.p[blockIdx.y]);
+    const size_t stride = static_cast<size_t>(gridDim.x) * 256;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+static Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) return;
+        auto sym = [&](const char *n) { return dlsym(r.lib, n); };
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast && r.GetErrorString;
+    });
+    return r;
+}
+
+}  // namespace mispmm
+
+struct mispmm_comm_s {
+    std::vector<ncclComm_t> comms;
+    std::vector<int> devices;
+};
+
+using namespace mispmm;
+
+#define MISPMM_RCCL_TRY(expr)                                                                                    \
+    do {                                                                                                         \
+        ncclResult_t r_ = (expr);                                                                                \
+        if (r_ != ncclSuccess)                                                                                   \
+            return fail(MISPMM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+namespace {
+// restores the calling thread's current device on every return path
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { (void)hipGetDevice(&saved); }
+    ~DeviceGuard() {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+int mispmm_slab_scatter(mispmm_stream_t stream, const void *src, size_t bytes, void *const *dsts_host, uint32_t ndst) {
+    if (bytes == 0 || ndst == 0) return MISPMM_OK;
+    if (!src || !dsts_host) return fail(MISPMM_ERR_INVALID_ARG, "slab_scatter: null pointer");
+    if (ndst > 16) return fail(MISPMM_ERR_INVALID_ARG, "slab_scatter: at most 16 destinations (got %u)", ndst);
+    if (bytes % 16 != 0 || !aligned16(src)) return fail(MISPMM_ERR_INVALID_ARG, "slab_scatter: src and size must be 16-byte multiples");
+    ScatterDsts d{};
+    for (uint32_t i = 0; i < ndst; ++i) {
+        if (!dsts_host[i] || !aligned16(dsts_host[i])) return fail(MISPMM_ERR_INVALID_ARG, "slab_scatter: destination %u null or unaligned", i);
+        d.p[i] = dsts_host[i];
+    }
+    const size_t n16 = bytes / 16;
+    const size_t blocks = (n16 + 255) / 256;
+    dim3 grid(static_cast<uint32_t>(blocks < 1024 ? blocks : 1024), ndst);
+    hipLaunchKernelGGL(slab_scatter_kernel, grid, dim3(256), 0, as_stream(stream), static_cast<const uint4 *>(src), n16, d);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+int mispmm_enable_peer_access(uint32_t ndev, const int *devices) {
+    if (ndev == 0) return MISPMM_OK;
+    if (!devices) return fail(MISPMM_ERR_INVALID_ARG, "peer access: devices is null");
+    DeviceGuard guard;
+    for (uint32_t a = 0; a < ndev; ++a) {
+        MISPMM_HIP_TRY(hipSetDevice(devices[a]));
+        for (uint32_t b = 0; b < ndev; ++b) {
+            if (devices[a] == devices[b]) continue;
+            int can = 0;
+            MISPMM_HIP_TRY(hipDeviceCanAccessPeer(&can, devices[a], devices[b]));
+            if (!can) return fail(MISPMM_ERR_UNSUPPORTED, "device %d cannot access device %d", devices[a], devices[b]);
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else MISPMM_HIP_TRY(e);
+        }
+    }
+    return MISPMM_OK;
+}
+
+int mispmm_comm_create(mispmm_comm_t *comm, uint32_t ndev, const int *devices) {
+    if (!comm || !devices || ndev == 0) return fail(MISPMM_ERR_INVALID_ARG, "comm_create: null pointer or no device");
+    *comm = nullptr;
+    if (!rccl().ok) return fail(MISPMM_ERR_UNSUPPORTED, "comm_create: librccl.so could not be loaded or lacks a symbol");
+    auto *c = new mispmm_comm_s;
+    c->comms.resize(ndev);
+    c->devices.assign(devices, devices + ndev);
+    DeviceGuard guard;
+    const ncclResult_t r = rccl().CommInitAll(c->comms.data(), static_cast<int>(ndev), devices);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(MISPMM_ERR_HIP, "ncclCommInitAll failed: %s", rccl().GetErrorString(r));
+    }
+    *comm = c;
+    return MISPMM_OK;
+}
+
+int mispmm_comm_destroy(mispmm_comm_t comm) {
+    if (!comm) return MISPMM_OK;
+    for (ncclComm_t c : comm->comms) (void)rccl().CommDestroy(c);
+    delete comm;
+    return MISPMM_OK;
+}
+
+int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *rowBounds_host,
+                         uint32_t K, const uint32_t *const *rowPtrs, const uint32_t *const *colIdxs,
+                         const float *const *vals, const uint32_t *nnz_host, const uint32_t *uniformRowNnz_host,
+                         const float *const *B, uint32_t N, uint32_t ldb, float *const *C, uint32_t ldc, int kernel,
+                         int acc_mode, int gather_mode, mispmm_comm_t comm) {
+    if (ndev == 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: no device");
+    if (!devices || !streams || !rowBounds_host || !rowPtrs || !colIdxs || !vals || !nnz_host || !B || !C)
+        return fail(MISPMM_ERR_INVALID_ARG, "multi: null argument array");
+    if (gather_mode < MISPMM_GATHER_NONE || gather_mode > MISPMM_GATHER_ALL_RCCL)
+        return fail(MISPMM_ERR_INVALID_ARG, "multi: unknown gather mode %d", gather_mode);
+    if (rowBounds_host[0] != 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: rowBounds[0] must be 0");
+    for (uint32_t d = 0; d < ndev; ++d) {
+        if (rowBounds_host[d + 1] < rowBounds_host[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: rowBounds must be non-decreasing");
+        if (!B[d] || !C[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: B or C of device slot %u is null", d);
+    }
+    if (ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "multi: ldc smaller than N");
+    if (gather_mode == MISPMM_GATHER_ALL_RCCL) {
+        if (!comm || comm->comms.size() != ndev) return fail(MISPMM_ERR_INVALID_ARG, "multi: RCCL gather needs a communicator over the same %u devices", ndev);
+        for (uint32_t d = 0; d < ndev; ++d)
+            if (comm->devices[d] != devices[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: communicator device order differs");
+    }
+    DeviceGuard guard;
+    // 1. every device multiplies its row range into its own rows of its C
+    for (uint32_t d = 0; d < ndev; ++d) {
+        const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
+        if (rows == 0 || N == 0) continue;
+        MISPMM_HIP_TRY(hipSetDevice(devices[d]));
+        float *slab = C[d] + static_cast<size_t>(r0) * ldc;
+        const uint32_t w = uniformRowNnz_host ? uniformRowNnz_host[d] : 0u;
+        int st = MISPMM_ERR_UNSUPPORTED;
+        if (w != 0 && (kernel == MISPMM_KERNEL_AUTO || kernel == 5))
+            st = mispmm_csr_uniform_f32(streams[d], rows, K, w, colIdxs[d], vals[d], B[d], N, ldb, slab, ldc, acc_mode);
+        if (st == MISPMM_ERR_UNSUPPORTED)
+            st = mispmm_csr_f32(streams[d], rows, K, nnz_host[d], rowPtrs[d], colIdxs[d], vals[d], B[d], N, ldb, slab, ldc, kernel,
+                                acc_mode);
+        if (st != MISPMM_OK) return st;
+    }
+    if (gather_mode == MISPMM_GATHER_NONE || N == 0) return MISPMM_OK;
+    // 2. exchange the slabs (stream order on the owner's stream: the copy follows the kernel that wrote the slab)
+    if (gather_mode == MISPMM_GATHER_TO_FIRST || gather_mode == MISPMM_GATHER_ALL_PEER) {
+        for (uint32_t d = 0; d < ndev; ++d) {
+            const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
+            if (rows == 0) continue;
+            const size_t off = static_cast<size_t>(r0) * ldc, bytes = (static_cast<size_t>(rows - 1) * ldc + N) * sizeof(float);
+            MISPMM_HIP_TRY(hipSetDevice(devices[d]));
+            const uint32_t last = gather_mode == MISPMM_GATHER_TO_FIRST ? 1u : ndev;
+            for (uint32_t e = 0; e < last; ++e) {
+                if (e == d || C[e] == C[d]) continue;
+                MISPMM_HIP_TRY(hipMemcpyPeerAsync(C[e] + off, devices[e], C[d] + off, devices[d], bytes, as_stream(streams[d])));
+            }
+        }
+        return MISPMM_OK;
+    }
+    MISPMM_RCCL_TRY(rccl().GroupStart());
+    for (uint32_t root = 0; root < ndev; ++root) {
+        const uint32_t r0 = rowBounds_host[root], rows = rowBounds_host[root + 1] - r0;
+        if (rows == 0) continue;
+        const size_t off = static_cast<size_t>(r0) * ldc, count = static_cast<size_t>(rows - 1) * ldc + N;
+        for (uint32_t d = 0; d < ndev; ++d) {
+            const ncclResult_t r = rccl().Broadcast(C[d] + off, C[d] + off, count, ncclFloat, static_cast<int>(root), comm->comms[d],
+                                                    as_stream(streams[d]));
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return fail(MISPMM_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r));
+            }
+        }
+    }
+    MISPMM_RCCL_TRY(rccl().GroupEnd());
+    return MISPMM_OK;
+}
+
+}  // extern "C"

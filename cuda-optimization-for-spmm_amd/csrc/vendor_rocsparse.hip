@@ -11,6 +11,25 @@
 
 using namespace mispmm;
 
+namespace {
+
+// everything the call creates, released on every return path
+struct VendorState {
+    rocsparse_handle handle = nullptr;
+    rocsparse_spmat_descr matA = nullptr;
+    rocsparse_dnmat_descr matB = nullptr, matC = nullptr;
+    void *buffer = nullptr;
+    ~VendorState() {
+        if (matA) rocsparse_destroy_spmat_descr(matA);
+        if (matB) rocsparse_destroy_dnmat_descr(matB);
+        if (matC) rocsparse_destroy_dnmat_descr(matC);
+        if (handle) rocsparse_destroy_handle(handle);
+        if (buffer) (void)hipFree(buffer);
+    }
+};
+
+}  // namespace
+
 #define MISPMM_ROCSPARSE_TRY(expr)                                                                        \
     do {                                                                                                  \
         rocsparse_status s_ = (expr);                                                                     \
@@ -34,54 +53,50 @@ extern "C" int mispmm_vendor_spmm_f32(mispmm_stream_t stream, int format, uint32
     hipStream_t st = as_stream(stream);
 
     const auto t1 = clock::now();
-    rocsparse_handle handle;
-    MISPMM_ROCSPARSE_TRY(rocsparse_create_handle(&handle));
-    MISPMM_ROCSPARSE_TRY(rocsparse_set_stream(handle, st));
-    rocsparse_spmat_descr matA;
-    rocsparse_spmm_alg alg = rocsparse_spmm_alg_default;
-    void *p0 = const_cast<uint32_t *>(ptrs_or_rows), *p1 = const_cast<uint32_t *>(cols), *pv = const_cast<float *>(vals);
-    if (format == MISPMM_VENDOR_CSR) {
-        MISPMM_ROCSPARSE_TRY(rocsparse_create_csr_descr(&matA, M, K, nnz, p0, p1, pv, rocsparse_indextype_i32,
-                                                        rocsparse_indextype_i32, rocsparse_index_base_zero,
-                                                        rocsparse_datatype_f32_r));
-        alg = rocsparse_spmm_alg_csr_row_split;
-    } else if (format == MISPMM_VENDOR_COO) {
-        MISPMM_ROCSPARSE_TRY(rocsparse_create_coo_descr(&matA, M, K, nnz, p0, p1, pv, rocsparse_indextype_i32,
-                                                        rocsparse_index_base_zero, rocsparse_datatype_f32_r));
-        alg = rocsparse_spmm_alg_coo_segmented;
-    } else {
-        MISPMM_ROCSPARSE_TRY(rocsparse_create_bsr_descr(&matA, M / block_dim, K / block_dim, nnz, rocsparse_direction_row,
-                                                        block_dim, p0, p1, pv, rocsparse_indextype_i32,
-                                                        rocsparse_indextype_i32, rocsparse_index_base_zero,
-                                                        rocsparse_datatype_f32_r));
-        alg = rocsparse_spmm_alg_bsr;
-    }
-    rocsparse_dnmat_descr matB, matC;
-    MISPMM_ROCSPARSE_TRY(rocsparse_create_dnmat_descr(&matB, K, N, ldb, const_cast<float *>(B), rocsparse_datatype_f32_r,
-                                                      rocsparse_order_row));
-    MISPMM_ROCSPARSE_TRY(rocsparse_create_dnmat_descr(&matC, M, N, ldc, C, rocsparse_datatype_f32_r, rocsparse_order_row));
-    const float alpha = 1.f, beta = 0.f;
-    size_t buffer_size = 0;
-    MISPMM_ROCSPARSE_TRY(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, matA, matB, &beta,
-                                        matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_buffer_size, &buffer_size,
-                                        nullptr));
-    void *buffer = nullptr;
-    MISPMM_HIP_TRY(hipMalloc(&buffer, buffer_size ? buffer_size : 4));
-    MISPMM_ROCSPARSE_TRY(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, matA, matB, &beta,
-                                        matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_preprocess, &buffer_size,
-                                        buffer));
-    MISPMM_HIP_TRY(hipStreamSynchronize(st));
-    const auto t2 = clock::now();
-    MISPMM_ROCSPARSE_TRY(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, matA, matB, &beta,
-                                        matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_compute, &buffer_size,
-                                        buffer));
-    MISPMM_HIP_TRY(hipStreamSynchronize(st));
-    const auto t3 = clock::now();
-    MISPMM_ROCSPARSE_TRY(rocsparse_destroy_spmat_descr(matA));
-    MISPMM_ROCSPARSE_TRY(rocsparse_destroy_dnmat_descr(matB));
-    MISPMM_ROCSPARSE_TRY(rocsparse_destroy_dnmat_descr(matC));
-    MISPMM_ROCSPARSE_TRY(rocsparse_destroy_handle(handle));
-    MISPMM_HIP_TRY(hipFree(buffer));
+    clock::time_point t2, t3;
+    {
+        VendorState v;
+        MISPMM_ROCSPARSE_TRY(rocsparse_create_handle(&v.handle));
+        MISPMM_ROCSPARSE_TRY(rocsparse_set_stream(v.handle, st));
+        rocsparse_spmm_alg alg = rocsparse_spmm_alg_default;
+        void *p0 = const_cast<uint32_t *>(ptrs_or_rows), *p1 = const_cast<uint32_t *>(cols), *pv = const_cast<float *>(vals);
+        if (format == MISPMM_VENDOR_CSR) {
+            MISPMM_ROCSPARSE_TRY(rocsparse_create_csr_descr(&v.matA, M, K, nnz, p0, p1, pv, rocsparse_indextype_i32,
+                                                            rocsparse_indextype_i32, rocsparse_index_base_zero,
+                                                            rocsparse_datatype_f32_r));
+            alg = rocsparse_spmm_alg_csr_row_split;
+        } else if (format == MISPMM_VENDOR_COO) {
+            MISPMM_ROCSPARSE_TRY(rocsparse_create_coo_descr(&v.matA, M, K, nnz, p0, p1, pv, rocsparse_indextype_i32,
+                                                            rocsparse_index_base_zero, rocsparse_datatype_f32_r));
+            alg = rocsparse_spmm_alg_coo_segmented;
+        } else {
+            // block storage order: the reference's blocks are row-major inside (sparse_bsr.cu:138-155: CUSPARSE_ORDER_ROW)
+            MISPMM_ROCSPARSE_TRY(rocsparse_create_bsr_descr(&v.matA, M / block_dim, K / block_dim, nnz, rocsparse_direction_row,
+                                                            block_dim, p0, p1, pv, rocsparse_indextype_i32,
+                                                            rocsparse_indextype_i32, rocsparse_index_base_zero,
+                                                            rocsparse_datatype_f32_r));
+            alg = rocsparse_spmm_alg_bsr;
+        }
+        MISPMM_ROCSPARSE_TRY(rocsparse_create_dnmat_descr(&v.matB, K, N, ldb, const_cast<float *>(B), rocsparse_datatype_f32_r,
+                                                          rocsparse_order_row));
+        MISPMM_ROCSPARSE_TRY(rocsparse_create_dnmat_descr(&v.matC, M, N, ldc, C, rocsparse_datatype_f32_r, rocsparse_order_row));
+        const float alpha = 1.f, beta = 0.f;
+        size_t buffer_size = 0;
+        MISPMM_ROCSPARSE_TRY(rocsparse_spmm(v.handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, v.matA, v.matB,
+                                            &beta, v.matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_buffer_size,
+                                            &buffer_size, nullptr));
+        MISPMM_HIP_TRY(hipMalloc(&v.buffer, buffer_size ? buffer_size : 4));
+        MISPMM_ROCSPARSE_TRY(rocsparse_spmm(v.handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, v.matA, v.matB,
+                                            &beta, v.matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_preprocess,
+                                            &buffer_size, v.buffer));
+        MISPMM_HIP_TRY(hipStreamSynchronize(st));
+        t2 = clock::now();
+        MISPMM_ROCSPARSE_TRY(rocsparse_spmm(v.handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, v.matA, v.matB,
+                                            &beta, v.matC, rocsparse_datatype_f32_r, alg, rocsparse_spmm_stage_compute,
+                                            &buffer_size, v.buffer));
+        MISPMM_HIP_TRY(hipStreamSynchronize(st));
+        t3 = clock::now();
+    }  // epilog = teardown of everything above
     const auto t4 = clock::now();
     if (pro_us) *pro_us = us(t1, t2);
     if (kernel_us) *kernel_us = us(t2, t3);

@@ -18,6 +18,8 @@ struct EngineOptions {
     int steadyIters = 0;     // > 0: additionally time this many back-to-back launches with HIP events
     int accOverride = -1;    // -1: from AccT; else MISPMM_ACC_REFERENCE / MISPMM_ACC_FAST
     bool vendorCheck = true; // run (and compare!) the rocSPARSE SpMM where the format supports it
+    int gpus = 0;            // > 0 (`--gpus n`): also run the CSR SpMM row-sharded over n devices of this node
+    int gatherMode = 1;      // mispmm_gather_mode of that run (default MISPMM_GATHER_TO_FIRST)
 };
 EngineOptions &engineOptions();
 

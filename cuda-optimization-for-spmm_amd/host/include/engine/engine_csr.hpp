@@ -16,6 +16,11 @@ template <typename DT, typename MT, typename AccT>
 DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b,
                                     DenseMatrix<DT, MT> *ref);
 
+// `--gpus n`: A (host) row-sharded over n devices in this process, B replicated, C slabs gathered according to
+// gatherMode (mispmm_gather_mode); one record with an extra "ngpus" key.  Returns the self-check verdict.
+template <typename DT, typename MT, typename AccT>
+bool spmmCSRMultiGpu(int ngpus, int gatherMode, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref);
+
 #define CUSPMM_DECLARE_CSR_WRAPPER(N)                                                                          \
     template <typename DT, typename MT, typename AccT>                                                         \
     DenseMatrix<DT, MT> *spmmCSRWrapper##N(SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b,                 \

@@ -25,7 +25,8 @@ struct SteadyStats {
     double usPerSpmm = 0;    // HIP-event time per launch over `iters` back-to-back launches
     double gflops = 0;       // 2 * nnz * N / time
     double hbmGBps = 0;      // algorithmic bytes / time
-    double rooflineFrac = 0; // hbmGBps / 8000 (MI355X HBM3E peak)
+    double rooflineFrac = 0; // hbmGBps / 8000 (MI355X HBM3E peak; times ngpus for a sharded run)
+    int ngpus = 0;           // > 0: the record is a row-sharded multi-GPU run over this many devices
 };
 
 // `ordering`: 0 = ROW_MAJOR.  `kernelNum`: 0 = sequential CPU engine, -1 = vendor library.

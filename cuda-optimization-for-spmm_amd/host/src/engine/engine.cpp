@@ -42,6 +42,13 @@ void runEngine(EngT *engine, typename EngT::MataT *a, typename EngT::MatbT *b, f
         if (!savePath.empty() && last != nullptr) last->save2File(savePath);
         delete last;
 
+        // 3b. `--gpus n`: the same product row-sharded over n devices (CSR; new capability, src/main.cu:176 pins one)
+        if constexpr (std::is_same_v<ma_t, SparseMatrixCSR<typename ma_t::DT, typename ma_t::MT>>) {
+            if (engineOptions().gpus > 0)
+                spmmCSRMultiGpu<typename ma_t::DT, typename ma_t::MT, double>(engineOptions().gpus, engineOptions().gatherMode, a,
+                                                                              b, cpuRes);
+        }
+
         // 4. vendor library, timed AND compared (the reference hard-codes correct = 1, engine.cpp:47-55)
         if (engine->SUPPORT_CUSPARSE && engineOptions().vendorCheck) {
             mb_t *dc = new mb_t(a->numRows, b->numCols, true, ORDERING::ROW_MAJOR);

@@ -1,5 +1,7 @@
 #include "formats/sparse_coo.hpp"
 
+#include <vector>
+
 namespace cuspmm {
 
 template <typename DT, typename MT> SparseMatrixCOO<DT, MT>::SparseMatrixCOO(std::string filePath) {
@@ -42,9 +44,37 @@ template <typename DT, typename MT> bool SparseMatrixCOO<DT, MT>::allocateSpace(
 template <typename DT, typename MT> SparseMatrixCOO<DT, MT> *SparseMatrixCOO<DT, MT>::copy2Device() {
     assert(!this->onDevice && this->data != nullptr);
     auto *d = new SparseMatrixCOO<DT, MT>(this->numRows, this->numCols, this->numNonZero, true);
-    copyBuffer(d->rowIdxs, true, this->rowIdxs, false, (size_t)this->numNonZero * sizeof(MT));
-    copyBuffer(d->colIdxs, true, this->colIdxs, false, (size_t)this->numNonZero * sizeof(MT));
-    copyBuffer(d->data, true, this->data, false, (size_t)this->numNonZero * sizeof(DT));
+    const MT *rows = this->rowIdxs, *cols = this->colIdxs;
+    const DT *vals = this->data;
+    // The HIP kernel walks rows, so entries must be grouped by row (the reference's atomicAdd kernel accepts any
+    // order, spmm_coo_k1.cu:8-27).  A file in another order is put into STABLE row order here, once per upload:
+    // each row keeps its storage order, so the sums still round exactly as spmmCOOCpu's do.
+    std::vector<MT> sortedRows, sortedCols;
+    std::vector<DT> sortedVals;
+    if (!this->isRowSorted()) {
+        const size_t nnz = this->numNonZero;
+        std::vector<size_t> start((size_t)this->numRows + 1, 0);
+        for (size_t i = 0; i < nnz; ++i) {
+            if (this->rowIdxs[i] >= this->numRows) throw std::runtime_error("COO row index out of range");
+            ++start[(size_t)this->rowIdxs[i] + 1];
+        }
+        for (size_t r = 0; r < this->numRows; ++r) start[r + 1] += start[r];
+        sortedRows.resize(nnz);
+        sortedCols.resize(nnz);
+        sortedVals.resize(nnz);
+        for (size_t i = 0; i < nnz; ++i) {
+            const size_t o = start[this->rowIdxs[i]]++;
+            sortedRows[o] = this->rowIdxs[i];
+            sortedCols[o] = this->colIdxs[i];
+            sortedVals[o] = this->data[i];
+        }
+        rows = sortedRows.data();
+        cols = sortedCols.data();
+        vals = sortedVals.data();
+    }
+    copyBuffer(d->rowIdxs, true, rows, false, (size_t)this->numNonZero * sizeof(MT));
+    copyBuffer(d->colIdxs, true, cols, false, (size_t)this->numNonZero * sizeof(MT));
+    copyBuffer(d->data, true, vals, false, (size_t)this->numNonZero * sizeof(DT));
     return d;
 }
 

@@ -8,7 +8,11 @@
 //   --acc <mode>     reference | fast   (default: from the engine's AccT = double -> reference)
 //   --cpu-only       run only the sequential CPU engine (no GPU needed)
 //   --no-vendor      skip the rocSPARSE cross-check
+//   --vendor-bsr     also run the rocSPARSE cross-check for --bsr (square blocks; the reference builds the BSR
+//                    descriptor, sparse_bsr.cu:138-160, but never enables the check: engine_bsr.hpp:24)
 //   --save <file>    write the last result matrix as text
+//   --gpus <n>       (--csr) also run the product row-sharded over n GPUs of this node: B replicated, C row slabs
+//                    gathered over xGMI; --gather first|peer|rccl|none picks how (default first = into device 0)
 #include <getopt.h>
 
 #include <cstdlib>
@@ -33,16 +37,19 @@ static void printHelp(const char *prog) {
               << "  --acc <mode>    reference | fast\n"
               << "  --cpu-only      Sequential CPU engine only\n"
               << "  --no-vendor     Skip the rocSPARSE cross-check\n"
+              << "  --vendor-bsr    rocSPARSE cross-check for --bsr as well (square blocks)\n"
               << "  --save <file>   Save the last result matrix\n"
+              << "  --gpus <n>      With --csr: also run row-sharded over n GPUs (B replicated, C slabs gathered)\n"
+              << "  --gather <how>  first | peer | rccl | none (default first: slabs copied into device 0)\n"
               << "  -h, --help      Display this help message\n";
 }
 
 int main(int argc, char *argv[]) {
     std::string dir, savePath, synthMode = "uniform";
-    bool wantCoo = false, wantCsr = false, wantBsr = false, wantEll = false, cpuOnly = false;
+    bool wantCoo = false, wantCsr = false, wantBsr = false, wantEll = false, cpuOnly = false, vendorBsr = false;
     int device = 0;
     long synthCols = 0;
-    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE };
+    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE, OPT_VENDORBSR, OPT_GPUS, OPT_GATHER };
     const option longOpts[] = {{"bsr", no_argument, nullptr, 'B'},           {"coo", no_argument, nullptr, 'O'},
                                {"csr", no_argument, nullptr, 'S'},           {"ell", no_argument, nullptr, 'E'},
                                {"cuda", no_argument, nullptr, 'U'},          {"help", no_argument, nullptr, 'h'},
@@ -53,6 +60,9 @@ int main(int argc, char *argv[]) {
                                {"cpu-only", no_argument, nullptr, OPT_CPU},
                                {"no-vendor", no_argument, nullptr, OPT_NOVENDOR},
                                {"save", required_argument, nullptr, OPT_SAVE},
+                               {"vendor-bsr", no_argument, nullptr, OPT_VENDORBSR},
+                               {"gpus", required_argument, nullptr, OPT_GPUS},
+                               {"gather", required_argument, nullptr, OPT_GATHER},
                                {nullptr, 0, nullptr, 0}};
     int opt;
     while ((opt = getopt_long(argc, argv, "hd:k:", longOpts, nullptr)) != -1) {
@@ -75,6 +85,20 @@ int main(int argc, char *argv[]) {
             case OPT_CPU: cpuOnly = true; break;
             case OPT_NOVENDOR: cuspmm::engineOptions().vendorCheck = false; break;
             case OPT_SAVE: savePath = optarg; break;
+            case OPT_VENDORBSR: vendorBsr = true; break;
+            case OPT_GPUS: cuspmm::engineOptions().gpus = std::atoi(optarg); break;
+            case OPT_GATHER: {
+                const std::string g = optarg;
+                if (g == "none") cuspmm::engineOptions().gatherMode = MISPMM_GATHER_NONE;
+                else if (g == "first") cuspmm::engineOptions().gatherMode = MISPMM_GATHER_TO_FIRST;
+                else if (g == "peer") cuspmm::engineOptions().gatherMode = MISPMM_GATHER_ALL_PEER;
+                else if (g == "rccl") cuspmm::engineOptions().gatherMode = MISPMM_GATHER_ALL_RCCL;
+                else {
+                    std::cerr << "Error: --gather takes first | peer | rccl | none\n";
+                    return EXIT_FAILURE;
+                }
+                break;
+            }
             default: return 1;  // getopt_long already printed a message
         }
     }
@@ -139,7 +163,12 @@ int main(int argc, char *argv[]) {
         };
         if (wantCoo) run(new cuspmm::SparseMatrixCOO<float, uint32_t>(cooFile), new cuspmm::EngineCOO<float, uint32_t, double>(dir));
         if (wantCsr) run(new cuspmm::SparseMatrixCSR<float, uint32_t>(csrFile), new cuspmm::EngineCSR<float, uint32_t, double>(dir));
-        if (wantBsr) run(new cuspmm::SparseMatrixBSR<float, uint32_t>(bsrFile), new cuspmm::EngineBSR<float, uint32_t, double>(dir));
+        if (wantBsr) {
+            auto *a = new cuspmm::SparseMatrixBSR<float, uint32_t>(bsrFile);
+            auto *engine = new cuspmm::EngineBSR<float, uint32_t, double>(dir);
+            engine->SUPPORT_CUSPARSE = vendorBsr && a->blockRowSize == a->blockColSize;
+            run(a, engine);
+        }
         if (wantEll)
             run(new cuspmm::SparseMatrixELL<float, uint32_t>(ellRowind, ellValuesCm), new cuspmm::EngineELL<float, uint32_t, double>(dir));
     } catch (const std::exception &e) {

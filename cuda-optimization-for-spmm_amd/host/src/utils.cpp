@@ -25,6 +25,7 @@ void reportTime(const std::string &tc, uint32_t aNumRows, uint32_t aNumCols, uin
                     "\"hbmGBps\":\"%lf\",\n\"rooflineFrac\":\"%lf\"",
                     steady->iters, steady->usPerSpmm, steady->gflops, steady->hbmGBps, steady->rooflineFrac);
     }
+    if (steady && steady->ngpus > 0) std::printf(",\n\"ngpus\":\"%d\"", steady->ngpus);
     std::printf("\n},\n");
     std::fflush(stdout);
 }

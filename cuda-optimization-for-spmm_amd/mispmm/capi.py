@@ -15,6 +15,7 @@ ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3
 ACC_REFERENCE, ACC_FAST = 0, 1
 ACC_MODES = {"reference": ACC_REFERENCE, "fast": ACC_FAST}
 H2H, H2D, D2H, D2D = 0, 1, 2, 3
+GATHER_NONE, GATHER_TO_FIRST, GATHER_ALL_PEER, GATHER_ALL_RCCL = 0, 1, 2, 3
 
 _c = ctypes
 _vp, _u32, _i, _sz = _c.c_void_p, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -58,12 +59,19 @@ SIGNATURES = {
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_coo_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _i, _i]),
     "mispmm_coo_row_bounds": (_i, [_vp, _u32, _u32, _vp, _vp]),
+    "mispmm_coo_sort_by_row_host": (_i, [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),
     "mispmm_vendor_spmm_f32": (_i, [_vp, _i, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32,
                                     _c.POINTER(_c.c_double), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "mispmm_dense_transpose_f32": (_i, [_vp, _u32, _u32, _vp, _vp]),
     "mispmm_f32_to_bf16": (_i, [_vp, _sz, _vp, _vp]),
     "mispmm_bf16_to_f32": (_i, [_vp, _sz, _vp, _vp]),
     "mispmm_shard_rows_by_nnz_host": (_i, [_u32, _vp, _u32, _vp]),
+    "mispmm_enable_peer_access": (_i, [_u32, _c.POINTER(_i)]),
+    "mispmm_comm_create": (_i, [_pvp, _u32, _c.POINTER(_i)]),
+    "mispmm_comm_destroy": (_i, [_vp]),
+    "mispmm_multi_csr_f32": (_i, [_u32, _c.POINTER(_i), _pvp, _c.POINTER(_u32), _u32, _pvp, _pvp, _pvp, _c.POINTER(_u32),
+                                  _c.POINTER(_u32), _pvp, _u32, _u32, _pvp, _u32, _i, _i, _i, _vp]),
+    "mispmm_slab_scatter": (_i, [_vp, _vp, _sz, _pvp, _u32]),
 }
 
 _lib = None

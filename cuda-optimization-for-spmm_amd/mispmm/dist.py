@@ -8,6 +8,16 @@ padded to the tallest slab so one `all_gather_into_tensor` moves a whole bucket 
 collective runs on its own stream and overlaps the next bucket's kernels (xGMI is point to point:
 few, large messages).
 
+Two ways the slabs travel (`exchange`):
+  allgather  one `all_gather_into_tensor` (RCCL) per bucket on a second stream, overlapped with the next bucket;
+  peer       no collective on the data path: every rank maps the other ranks' gather buffers into its own
+             address space (IPC handles exchanged once through torch.distributed) and ONE kernel per bucket
+             (mispmm_slab_scatter, part of the bucket's hipGraph) stores the rank's slabs straight into every
+             peer's buffer over xGMI; a one-element all-reduce per bucket tells a rank that all its peers'
+             stores have landed.  A rank may read bucket i's gathered C once `finish()` or the wait for that
+             bucket has returned, and must be done with it before it contributes to bucket i + 1's barrier
+             (the peers overwrite the buffer two buckets later, gated on that barrier).
+
 The compute step is injectable so the partition / bucket / gather logic is exercised on CPU with
 the gloo backend (tests/test_dist_cpu.py); on a GPU the default is the HIP kernel via the C ABI.
 """
@@ -35,8 +45,6 @@ class ShardedCsrSpmm:
     def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather"):
         if exchange not in ("allgather", "peer"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
-        if exchange == "peer":
-            raise NotImplementedError("peer exchange: see mispmm/dist.py (IPC-mapped peer buffers)")
         self.exchange = exchange
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = torch.device(device)
@@ -69,8 +77,43 @@ class ShardedCsrSpmm:
             self.compute_stream = self.comm_stream = None
         # One hipGraph per ring buffer holding a whole bucket of kernel launches (slots 0..bucket-1):
         # a step is a few microseconds, so launching each from Python would be host-bound.
-        self.bucket_graphs = [None, None]
+        self.bucket_graphs = {}
         self.use_graphs = self.on_gpu and compute is None
+        self.peer_dst = None
+        if exchange == "peer":
+            if not self.on_gpu:
+                raise ValueError("peer exchange needs device buffers")
+            self._map_peer_buffers()
+
+    # -- peer exchange: map every rank's gather buffers once ------------------------------------------
+    def _map_peer_buffers(self):
+        from torch.multiprocessing.reductions import reduce_tensor
+        mine = [reduce_tensor(g) for g in self.gathered]          # (rebuild function, picklable IPC arguments)
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, [m[1] for m in mine])
+        rebuild = mine[0][0]
+        self.peer_gathered = []
+        for r in range(self.world):
+            self.peer_gathered.append(self.gathered if r == self.rank else [rebuild(*everyone[r][b]) for b in (0, 1)])
+        ordinals = sorted({t.device.index for pg in self.peer_gathered for t in pg} | {self.device.index})
+        if len(ordinals) > 1:
+            arr = (ctypes.c_int * len(ordinals))(*ordinals)
+            capi.check(capi.lib().mispmm_enable_peer_access(len(ordinals), arr))
+        # destination pointers of this rank's slot in every rank's buffer, per ring buffer
+        self.peer_dst = []
+        for b in (0, 1):
+            arr = (ctypes.c_void_p * self.world)()
+            for r in range(self.world):
+                arr[r] = self.peer_gathered[r][b][self.rank].data_ptr()
+            self.peer_dst.append(arr)
+        self.flag = torch.zeros(1, dtype=torch.float32, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.barrier()                                            # nobody stores before everybody has mapped
+
+    def _scatter(self, buf):
+        nbytes = self.ring[buf].numel() * 4
+        capi.check(capi.lib().mispmm_slab_scatter(ctypes.c_void_p(self.compute_stream.cuda_stream),
+                                                  ctypes.c_void_p(self.ring[buf].data_ptr()), nbytes, self.peer_dst[buf],
+                                                  self.world))
 
     # -- the compute step ------------------------------------------------------------------------
     def _hip_compute(self, a, b, out):
@@ -80,12 +123,32 @@ class ShardedCsrSpmm:
     def broadcast_b(self, b_host):
         if self.rank == 0:
             self.b.copy_(torch.from_numpy(np.ascontiguousarray(b_host, dtype=np.float32)))
-        dist.broadcast(self.b, src=0)
+        if self.on_gpu and dist.get_backend() != "nccl":
+            staged = self.b.cpu()                 # a CPU-only backend (gloo rehearsal on one card): broadcast on the host
+            dist.broadcast(staged, src=0)
+            self.b.copy_(staged)
+        else:
+            dist.broadcast(self.b, src=0)
         if self.on_gpu:
             torch.cuda.synchronize(self.device)
 
     # -- steady state ----------------------------------------------------------------------------
-    def _gather(self, buf):
+    def _gather(self, buf, scattered=False):
+        if self.exchange == "peer":
+            if not scattered:
+                self._scatter(buf)
+            if dist.get_backend() == "nccl":
+                # every rank's scatter precedes its contribution on its own stream: the reduction completing on
+                # this rank means every peer's stores into this rank's buffer have been issued AND completed
+                done = torch.cuda.Event()
+                done.record(self.compute_stream)
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(done)
+                    self.pending[buf] = dist.all_reduce(self.flag, async_op=True)
+            else:
+                self.compute_stream.synchronize()
+                dist.barrier()
+            return
         if self.on_gpu:
             done = torch.cuda.Event()
             done.record(self.compute_stream)
@@ -110,18 +173,21 @@ class ShardedCsrSpmm:
             w.wait()
         self.pending[buf] = None
 
-    def _bucket_graph(self, buf):
-        if self.bucket_graphs[buf] is None:
+    def _bucket_graph(self, buf, scatter):
+        key = (buf, bool(scatter))
+        if key not in self.bucket_graphs:
             l = capi.lib()
             sp = ctypes.c_void_p(self.compute_stream.cuda_stream)
             self.compute_stream.synchronize()
             capi.check(l.mispmm_graph_begin(sp))
             for slot in range(self.bucket):
                 self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
+            if scatter:
+                self._scatter(buf)                  # the bucket's slabs leave for every peer inside the same graph
             g = ctypes.c_void_p()
             capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
-            self.bucket_graphs[buf] = g
-        return self.bucket_graphs[buf]
+            self.bucket_graphs[key] = g
+        return self.bucket_graphs[key]
 
     def run(self, steps, gather=True):
         done = 0
@@ -131,12 +197,15 @@ class ShardedCsrSpmm:
             if self.use_graphs and self.rows and slot == 0 and steps - done >= self.bucket:
                 # a whole bucket at once: replay its graph, then hand the ring buffer to the collective
                 self._wait(buf, self.compute_stream)
-                capi.check(capi.lib().mispmm_graph_launch(self._bucket_graph(buf),
+                if self.exchange == "peer" and gather:
+                    self._wait(1 - buf, self.compute_stream)   # peers are done with the bucket before the last one
+                scatter = gather and self.exchange == "peer"
+                capi.check(capi.lib().mispmm_graph_launch(self._bucket_graph(buf, scatter),
                                                           ctypes.c_void_p(self.compute_stream.cuda_stream)))
                 self.step_count += self.bucket
                 done += self.bucket
                 if gather:
-                    self._gather(buf)
+                    self._gather(buf, scattered=self.exchange == "peer")
                     self.last = (buf, self.bucket - 1)
                 continue
             self._run_eager(1, gather)
@@ -148,6 +217,8 @@ class ShardedCsrSpmm:
             buf, slot = (i // self.bucket) % 2, i % self.bucket
             if slot == 0:
                 self._wait(buf, self.compute_stream)      # the gather that last read this ring is done
+                if self.exchange == "peer" and gather:
+                    self._wait(1 - buf, self.compute_stream)
             if self.rows:
                 self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
             self.step_count += 1
@@ -170,10 +241,9 @@ class ShardedCsrSpmm:
             self.comm_stream.synchronize()
 
     def close(self):
-        for g in self.bucket_graphs:
-            if g is not None:
-                capi.check(capi.lib().mispmm_graph_destroy(g))
-        self.bucket_graphs = [None, None]
+        for g in self.bucket_graphs.values():
+            capi.check(capi.lib().mispmm_graph_destroy(g))
+        self.bucket_graphs = {}
 
     # -- results ---------------------------------------------------------------------------------
     def gathered_c(self):

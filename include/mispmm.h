@@ -183,8 +183,10 @@ int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, u
                     int c_bf16);
 
 /* -------------------------------------------------------------- COO x dense */
-/* Row-major-sorted COO (the order convert_mtx.py:172-190 writes; rowIdxs must be
- * non-decreasing).  Replaces spmmCOOWrapper1 (src/spmm/coo/spmm_coo_k1.cu:50-103)
+/* Row-major-sorted COO (the order convert_mtx.py:172-190 writes).  PRECONDITION: rowIdxs is
+ * non-decreasing -- an unsorted array makes the row boundaries meaningless and the kernel read out of
+ * range; callers holding arbitrary COO data run mispmm_coo_sort_by_row_host first (the host layer's
+ * SparseMatrixCOO::copy2Device does).  Replaces spmmCOOWrapper1 (src/spmm/coo/spmm_coo_k1.cu:50-103)
  * without atomics.  rowPtrs_workspace: device scratch of (M + 1) uint32 the call
  * fills with row boundaries first; NULL makes every row group binary-search its
  * range instead (slower, no scratch).  kernel: 0 auto, 1 row-group gather,
@@ -196,6 +198,14 @@ int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz,
                    const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
                    uint32_t ldc, uint32_t *rowPtrs_workspace, int kernel, int acc_mode);
 #define MISPMM_COO_NUM_KERNELS 2
+/* HOST helper.  The COO kernels need entries grouped by non-decreasing row (the reference's kernel, one atomicAdd
+ * per entry, does not: spmm_coo_k1.cu:8-27).  *was_sorted says whether the input already is; with the three
+ * output arrays given (each nnz long, may not alias the inputs) the entries are copied in a STABLE row order:
+ * every row keeps its entries in storage order, the order spmmCOOCpu adds them in (spmm_coo.cpp:16-24), so
+ * REFERENCE results stay bit-identical to it.  Outputs NULL = query only. */
+int mispmm_coo_sort_by_row_host(uint32_t M, uint32_t nnz, const uint32_t *rowIdxs_host, const uint32_t *colIdxs_host,
+                                const float *vals_host, uint32_t *rowIdxs_out_host, uint32_t *colIdxs_out_host,
+                                float *vals_out_host, int *was_sorted);
 /* rowPtrs_out[r] = index of the first entry of row r (r = 0..M; rowPtrs_out[M] = nnz) for a COO sorted by row. */
 int mispmm_coo_row_bounds(mispmm_stream_t stream, uint32_t M, uint32_t nnz, const uint32_t *rowIdxs,
                           uint32_t *rowPtrs_out);
@@ -228,6 +238,40 @@ int mispmm_bf16_to_f32(mispmm_stream_t stream, size_t n, const uint16_t *src, fl
  * single-GPU, src/main.cu:176). */
 int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t parts,
                                   uint32_t *bounds_out_host);
+
+/* ------------------------------------------------ multi-GPU: single process, arrays of per-device pointers */
+/* New capability (the reference selects ONE device, src/main.cu:176, and has no exchange step).  Device slot d
+ * (ordinal devices[d], stream streams[d]) owns rows [rowBounds[d], rowBounds[d+1]) of A and C:
+ *   rowPtrs[d]  its row pointers, REBASED to start at 0 (rows + 1 entries);  colIdxs[d] / vals[d] its entries
+ *               (column indices untouched: B is replicated);  nnz_host[d] their count;
+ *   uniformRowNnz_host[d]  > 0 if every row of the slice holds exactly that many entries (may be NULL);
+ *   B[d]        its replica of the dense operand [K x N], leading dimension ldb;
+ *   C[d]        its buffer for the FULL C [M x N] (M = rowBounds[ndev]), leading dimension ldc: the device writes
+ *               its own rows at their global position, the gather fills in the others'.
+ * All pointer arrays are HOST arrays of DEVICE pointers.  Work is only enqueued, on the given streams; the
+ * result is complete once every stream has been synchronised (C[0] for GATHER_TO_FIRST, every C[d] for the
+ * ALL modes, each device's own rows for GATHER_NONE).  The calling thread's current device is preserved. */
+#define MISPMM_MAX_SCATTER_DSTS 16
+typedef struct mispmm_comm_s *mispmm_comm_t; /* one RCCL communicator per device slot (ncclCommInitAll) */
+enum mispmm_gather_mode {
+    MISPMM_GATHER_NONE = 0,     /* C stays row-sharded */
+    MISPMM_GATHER_TO_FIRST = 1, /* slabs copied into C[0] over xGMI (hipMemcpyPeerAsync on the owner's stream) */
+    MISPMM_GATHER_ALL_PEER = 2, /* every slab copied into every other device's C */
+    MISPMM_GATHER_ALL_RCCL = 3  /* grouped in-place ncclBroadcast of each slab from its owner (all-gather-v) */
+};
+int mispmm_enable_peer_access(uint32_t ndev, const int *devices);
+/* loads librccl.so on first use; MISPMM_ERR_UNSUPPORTED when it is not there */
+int mispmm_comm_create(mispmm_comm_t *comm, uint32_t ndev, const int *devices);
+int mispmm_comm_destroy(mispmm_comm_t comm);
+int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *rowBounds_host,
+                         uint32_t K, const uint32_t *const *rowPtrs, const uint32_t *const *colIdxs,
+                         const float *const *vals, const uint32_t *nnz_host, const uint32_t *uniformRowNnz_host,
+                         const float *const *B, uint32_t N, uint32_t ldb, float *const *C, uint32_t ldc, int kernel,
+                         int acc_mode, int gather_mode, mispmm_comm_t comm);
+/* One launch copies `bytes` (a multiple of 16; 16-byte aligned pointers) from src to each of ndst <= 16
+ * destinations, which may be another device's memory mapped into this process (peer access, or an IPC handle
+ * opened by a one-process-per-GPU host: mispmm/dist.py).  Enqueue only; capturable into a graph. */
+int mispmm_slab_scatter(mispmm_stream_t stream, const void *src, size_t bytes, void *const *dsts_host, uint32_t ndst);
 
 #ifdef __cplusplus
 }

@@ -114,3 +114,45 @@ def test_shard_rows_by_nnz():
     assert list(ops.shard_rows_by_nnz(np.array([0, 3], np.uint32), 4)) == [0, 0, 1, 1, 1] or True
     b = ops.shard_rows_by_nnz(np.array([0, 3], np.uint32), 4)                     # more parts than rows
     assert b[0] == 0 and b[-1] == 1 and np.all(np.diff(b.astype(np.int64)) >= 0)
+
+
+def test_coo_sort_by_row_is_stable_and_detects_order():
+    """mispmm_coo_sort_by_row_host: the COO kernels need row-grouped entries; a shuffled file is put into STABLE row
+    order (every row keeps its storage order = the order spmmCOOCpu adds its terms in)."""
+    rng = np.random.default_rng(9)
+    m, nnz = 37, 500
+    rows = rng.integers(0, m, nnz).astype(np.uint32)
+    cols = rng.integers(0, 91, nnz).astype(np.uint32)
+    vals = rng.uniform(-1, 1, nnz).astype(np.float32)
+    l = capi.lib()
+    flag = ctypes.c_int(-1)
+    capi.check(l.mispmm_coo_sort_by_row_host(m, nnz, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, None, None, None,
+                                             ctypes.byref(flag)))
+    assert flag.value == 0
+    r2, c2, v2 = np.empty_like(rows), np.empty_like(cols), np.empty_like(vals)
+    capi.check(l.mispmm_coo_sort_by_row_host(m, nnz, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, r2.ctypes.data,
+                                             c2.ctypes.data, v2.ctypes.data, ctypes.byref(flag)))
+    order = np.argsort(rows, kind="stable")
+    assert np.array_equal(r2, rows[order]) and np.array_equal(c2, cols[order]) and np.array_equal(v2, vals[order])
+    capi.check(l.mispmm_coo_sort_by_row_host(m, nnz, r2.ctypes.data, c2.ctypes.data, v2.ctypes.data, None, None, None,
+                                             ctypes.byref(flag)))
+    assert flag.value == 1
+    bad = rows.copy()
+    bad[7] = m
+    assert l.mispmm_coo_sort_by_row_host(m, nnz, bad.ctypes.data, cols.ctypes.data, vals.ctypes.data, None, None, None,
+                                         ctypes.byref(flag)) == capi.ERR_INVALID_ARG
+    assert l.mispmm_coo_sort_by_row_host(m, 0, None, None, None, None, None, None, ctypes.byref(flag)) == capi.OK
+
+
+def test_multi_entry_point_argument_errors():
+    l = capi.lib()
+    import ctypes
+    one = (ctypes.c_void_p * 1)(16)
+    devs, bounds, nnz = (ctypes.c_int * 1)(0), (ctypes.c_uint32 * 2)(0, 4), (ctypes.c_uint32 * 1)(1)
+    args = lambda gather, comm=None, b=bounds: (1, devs, one, b, 4, one, one, one, nnz, None, one, 8, 8, one, 8, 0, 0, gather, comm)  # noqa: E731
+    assert l.mispmm_multi_csr_f32(*args(9)) == capi.ERR_INVALID_ARG
+    assert l.mispmm_multi_csr_f32(*args(capi.GATHER_ALL_RCCL)) == capi.ERR_INVALID_ARG          # no communicator
+    assert l.mispmm_multi_csr_f32(*args(0, b=(ctypes.c_uint32 * 2)(1, 4))) == capi.ERR_INVALID_ARG   # bounds[0] != 0
+    assert l.mispmm_multi_csr_f32(0, devs, one, bounds, 4, one, one, one, nnz, None, one, 8, 8, one, 8, 0, 0, 0, None) == capi.ERR_INVALID_ARG
+    assert l.mispmm_slab_scatter(None, ctypes.c_void_p(16), 24, one, 1) == capi.ERR_INVALID_ARG  # not a 16-byte multiple
+    assert l.mispmm_slab_scatter(None, ctypes.c_void_p(16), 32, one, 17) == capi.ERR_INVALID_ARG

@@ -141,8 +141,70 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
     recs = [r for r, _ in records(p.stdout)]
     assert [r["kernelType"] for r in recs if r["format"] == "CSR"] == ["0", "1", "2", "3", "4", "5", "-1"]
     assert all(r["correct"] == "1" for r in recs)
-    best = max(float(r["rooflineFrac"]) for r in recs if "rooflineFrac" in r)
-    assert best > 0.2, "steady-state HBM roofline fraction collapsed"
+    # perf guard, a few percent under the kept numbers (profiles/r2): the CLI times eager back-to-back launches
+    # (host-bound below ~3.5 us per kernel), so its floor sits lower than bench.py's graph-replay figure
+    best = {}
+    for r in recs:
+        if "rooflineFrac" in r and r["kernelType"] not in ("0", "-1"):
+            best[r["format"]] = max(best.get(r["format"], 0.0), float(r["rooflineFrac"]))
+    assert best["CSR"] >= 0.40, f"CSR K=128 steady-state HBM roofline fraction regressed: {best}"
+    assert best["ELL"] >= 0.40, f"ELL K=128 steady-state HBM roofline fraction regressed: {best}"
+
+
+@pytest.mark.gpu
+def test_bench_line_perf_floors():
+    """bench.py at the driver's flags: the headline and the ELL K=256 configuration must stay within a few percent of
+    the kept numbers (profiles/r2/bench_*.json: 0.59-0.60 and 0.64-0.65 of the 8 TB/s roofline), and the line must
+    carry the contract's fields."""
+    import json
+    import sys
+    for cfg, floor in (("headline", 0.55), ("3", 0.60)):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "20", "--warmup", "5",
+                            "--cpu-seconds", "1", "--no-extras"], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in line, key
+        assert line["steps"] == 20 and line["warmup"] == 5 and line["cpu_baseline"]["gpu_parity"] == "bit-exact"
+        assert line["roofline"]["frac"] >= floor, (cfg, line["roofline"])
+
+
+@pytest.mark.gpu
+def test_cli_accepts_a_coo_file_in_any_entry_order(tmp_path):
+    """The reference's COO kernel (one atomicAdd per entry) takes entries in any order; the row-walking HIP kernel
+    needs them grouped by row, so SparseMatrixCOO::copy2Device puts a shuffled file into stable row order.  A
+    shuffled .coo must give `correct: 1` for every kernel and the vendor check."""
+    from mispmm import datasets, formats
+    d = tmp_path / "shuffled"
+    d.mkdir()
+    csr = datasets.load_csr("qh1484", dtype=np.float64)
+    coo = formats.csr_to_coo(csr)
+    perm = np.random.default_rng(3).permutation(coo.nnz)
+    shuffled = formats.COO(coo.num_rows, coo.num_cols, coo.row_idxs[perm], coo.col_idxs[perm], coo.data[perm])
+    formats.write_coo(d / "qh1484.coo", shuffled)
+    p = run_cli("--coo", "-k", "64", "-d", str(d))
+    recs = [r for r, _ in records(p.stdout)]
+    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "-1"]
+    assert all(r["correct"] == "1" for r in recs), [(r["kernelType"], r["correct"]) for r in recs]
+
+
+@pytest.mark.gpu
+def test_cli_vendor_check_for_bsr(tmp_path):
+    """--vendor-bsr: rocSPARSE BSR SpMM (the descriptor the reference builds at sparse_bsr.cu:138-160 but never uses)
+    is timed and compared like the CSR / COO checks."""
+    from mispmm import datasets, formats
+    d = tmp_path / "bsr4"
+    d.mkdir()
+    csr = datasets.load_csr("qh1484", dtype=np.float64)
+    formats.write_bsr(d / "qh1484.bsr", formats.csr_to_bsr(csr, 4))
+    p = run_cli("--bsr", "--vendor-bsr", "-k", "64", "-d", str(d))
+    recs = [r for r, _ in records(p.stdout)]
+    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "-1"]
+    assert recs[1]["correct"] == "1" and recs[3]["correct"] == "1", [(r["kernelType"], r["correct"]) for r in recs]
+    # without the flag the BSR engine reports what the reference's does: no vendor record
+    p = run_cli("--bsr", "-k", "64", "-d", str(d))
+    assert [r["kernelType"] for r, _ in records(p.stdout)] == ["0", "1", "2"]
 
 
 def test_validate_tool_checks_cli_dumps(tmp_path, golden_dir):
@@ -168,3 +230,22 @@ def test_validate_tool_checks_cli_dumps(tmp_path, golden_dir):
     np.savetxt(d / "broken.out", bad)
     p = subprocess.run([sys.executable, tool, str(d), "--rtol", "1e-5", "--atol", "1e-6"], capture_output=True, text=True)
     assert p.returncode == 1 and "broken.out does NOT match" in p.stdout
+
+
+@pytest.mark.gpu
+def test_cli_row_sharded_run_behind_the_gpus_flag(tmp_path):
+    """`cuspmm --csr -k 512 --gpus 1` (BASELINE config 5's shape on the one card of the test box): the row-sharded run
+    goes through mispmm_multi_csr_f32 and adds one record carrying `ngpus`; every gather mode agrees with the CPU engine."""
+    from mispmm import datasets, formats
+    d = tmp_path / "large_25605"
+    d.mkdir()
+    formats.write_csr(d / "n4c6-b13.csr", datasets.load_csr("n4c6-b13", dtype=np.float64), integer=True)
+    for gather in ("first", "peer", "rccl", "none"):
+        p = run_cli("--csr", "-k", "512", "--gpus", "1", "--gather", gather, "--no-vendor", "--iters", "20", "-d", str(d))
+        recs = [r for r, _ in records(p.stdout)]
+        multi = [r for r in recs if "ngpus" in r]
+        assert len(multi) == 1 and multi[0]["ngpus"] == "1" and multi[0]["correct"] == "1", (gather, multi)
+        assert float(multi[0]["gflops"]) > 0
+        assert [r["kernelType"] for r in recs if "ngpus" not in r] == ["0", "1", "2", "3", "4", "5"]
+    p = run_cli("--csr", "-k", "8", "--gpus", "99", "-d", str(d), check=False)
+    assert p.returncode != 0 and "--gpus 99" in p.stderr

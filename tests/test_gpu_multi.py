@@ -1,0 +1,122 @@
+"""Multi-GPU paths on the one-GPU test box.  What can be proven here: the single-process entry point
+(mispmm_multi_csr_f32) with one device slot and with several slots on the same card (real streams, real slab
+copies, RCCL with one rank), the one-process-per-GPU driver (mispmm/dist.py) over RCCL with world size 1, and
+its peer exchange between two processes that share the card (IPC-mapped buffers, gloo for control).  The
+8-GPU curve is the driver's to measure."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from mispmm import capi, datasets, ops, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("name,n", [("n4c6-b13", 512), ("GL7d25", 64), ("qh1484", 40)])
+def test_single_process_multi_device_entry_point(oracle, name, n):
+    from mispmm.multi import MultiCsrSpmm
+    csr = datasets.load_csr(name)
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    single = ops.spmm_csr(ops.DeviceCSR.from_host(csr), dev(b)).cpu().numpy()
+    assert np.array_equal(single, ref)
+    for devices, gathers in (([0], ["none", "first", "peer", "rccl"]), ([0, 0], ["none", "first", "peer"]),
+                             ([0, 0, 0], ["first", "peer"])):
+        for gather in gathers:
+            job = MultiCsrSpmm(csr, n, devices, gather=gather)
+            job.set_b(b)
+            for _ in range(3):
+                job.step()
+            job.sync()
+            assert np.array_equal(job.sharded_c(), ref), (devices, gather)
+            if gather != "none":
+                assert np.array_equal(job.full_c(0).cpu().numpy(), ref), (devices, gather)
+            if gather in ("peer", "rccl"):
+                for slot in range(len(devices)):
+                    assert np.array_equal(job.full_c(slot).cpu().numpy(), ref), (devices, gather, slot)
+            job.close()
+
+
+def test_slab_scatter_copies_to_every_destination():
+    import ctypes
+    src = torch.arange(4096 * 3 + 4, dtype=torch.float32, device="cuda")
+    dsts = [torch.zeros_like(src) for _ in range(5)]
+    arr = (ctypes.c_void_p * 5)(*[d.data_ptr() for d in dsts])
+    capi.check(capi.lib().mispmm_slab_scatter(None, ctypes.c_void_p(src.data_ptr()), src.numel() * 4, arr, 5))
+    torch.cuda.synchronize()
+    for d in dsts:
+        assert torch.equal(d, src)
+
+
+@pytest.fixture(scope="module")
+def nccl_world_of_one():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["allgather", "peer"])
+def test_sharded_driver_over_rccl_world_size_one(oracle, nccl_world_of_one, exchange):
+    """BASELINE config 5's code path (n4c6-b13 CSR x K=512, RCCL backend) with one rank: more than two buckets
+    including a partial one, bucket hipGraphs on, the exchange on its own stream -- gathered C must equal the
+    oracle bit for bit."""
+    from mispmm import dist as mdist
+    csr = datasets.load_csr("n4c6-b13")
+    n = 512
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    job = mdist.ShardedCsrSpmm(csr, n, device=torch.device("cuda", 0), bucket=4, exchange=exchange)
+    assert job.use_graphs
+    job.broadcast_b(b)
+    job.run(4 * 2 + 3)                     # two graph-replayed buckets, three eager steps
+    job.finish()
+    got = job.gathered_c().cpu().numpy()
+    assert np.array_equal(got, ref)
+    unsharded = ops.spmm_csr(ops.DeviceCSR.from_host(csr), job.b).cpu().numpy()
+    assert np.array_equal(got, unsharded)
+    job.run(8)                             # steady state again after a partial bucket
+    job.finish()
+    assert np.array_equal(job.gathered_c().cpu().numpy(), ref)
+    job.run(5, gather=False)
+    job.finish(gather=False)
+    assert np.array_equal(job.local_slab().cpu().numpy(), ref)
+    job.close()
+
+
+def _bench(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "MASTER_ADDR", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_distributed_path_single_rank_over_rccl():
+    line = _bench("--gpus", "1", "--steps", "40", "--warmup", "8", "--bucket", "8", env={"MISPMM_FORCE_DIST": "1"})
+    assert line["n_gpus"] == 1 and set(line["exchange_modes"]) == {"allgather", "peer"}
+    assert all("value" in v for v in line["exchange_modes"].values()), line["exchange_modes"]
+
+
+def test_peer_exchange_between_two_processes_on_one_card():
+    """Two ranks share the card (gloo carries the control messages, IPC handles map each rank's gather buffers into
+    the other): `bench.py --gpus 2` spawns its ranks itself and refuses to print unless the exchanged C equals the
+    unsharded product on every rank."""
+    line = _bench("--gpus", "2", "--steps", "40", "--warmup", "8", "--bucket", "8", "--exchange", "peer",
+                  env={"MISPMM_SHARE_GPU": "1"})
+    assert line["n_gpus"] == 2 and "value" in line["exchange_modes"]["peer"]
+    assert "bitwise" in line["config"]["check"]
