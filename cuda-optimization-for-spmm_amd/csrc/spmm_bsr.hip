@@ -23,6 +23,7 @@
 // fp32 MFMA runs at the fp32 vector rate and is MFMA-bound on low-fill blocks.
 #include <cstdlib>
 
+#include "bsr_bf16_lds.hpp"
 #include "spmm_common.hpp"
 
 namespace mispmm {
@@ -718,6 +719,32 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
             if (c_bf16) MISPMM_BF16_LAUNCH(KERNEL, 4, true); else MISPMM_BF16_LAUNCH(KERNEL, 4, false); \
         }                                                                                        \
     } while (0)
+    // MISPMM_BSR_LDS=1: the LDS-staged kernel (bsr_bf16_lds.hpp: LDS-DMA ring + ds_read_b64_tr_b16, the plan of round 1).
+    // Passes the same parity tests as the register-staged kernel below but is SLOWER on config 4 (14.9 us at ring depth 4,
+    // 15.9 at 6, 18.1 at 8, against 11.4 us; profiles/r2/bsr_bf16_variants.log), so it stays opt-in.
+    static const bool bsr_lds = [] { const char *e = getenv("MISPMM_BSR_LDS"); return e && e[0] == '1'; }();
+    const uint64_t blocks_bytes = static_cast<uint64_t>(numBlocks) * 512u;
+    if (bR == 16 && bsr_lds && N % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && aligned16(B) && aligned16(C) && aligned16(blocks) &&
+        blocks_bytes <= 0x7FFFFFFFull) {
+        const uint32_t nst = ceil_div(N, 64u);
+        const XcdGrid g = xcd_grid(numBlockRows * nst);
+        // ring depth 4 (3 block pairs = 15 KiB in flight per workgroup, 8 workgroups per CU); MISPMM_BSR_DEPTH=6|8 deepens it
+        static const int depth = [] { const char *e = getenv("MISPMM_BSR_DEPTH"); return e ? atoi(e) : 4; }();
+        note_kernel("bsr_bf16_lds<%s,D%d>", c_bf16 ? "c16" : "c32", depth == 4 ? 4 : depth == 6 ? 6 : 8);
+#define MISPMM_LDS_LAUNCH(CB, DD)                                                                                              \
+    hipLaunchKernelGGL((bsr_bf16_lds<CB, DD>), dim3(g.grid), dim3(128), 0, as_stream(stream), numBlockRows, nst, blockRowPtrs, \
+                       blockColIdxs, blocks, static_cast<uint32_t>(blocks_bytes), B, b_bytes, N, ldb, C, ldc, g.chunk)
+        if (depth == 4) {
+            if (c_bf16) MISPMM_LDS_LAUNCH(true, 4); else MISPMM_LDS_LAUNCH(false, 4);
+        } else if (depth == 6) {
+            if (c_bf16) MISPMM_LDS_LAUNCH(true, 6); else MISPMM_LDS_LAUNCH(false, 6);
+        } else {
+            if (c_bf16) MISPMM_LDS_LAUNCH(true, 8); else MISPMM_LDS_LAUNCH(false, 8);
+        }
+#undef MISPMM_LDS_LAUNCH
+        MISPMM_LAUNCH_CHECK();
+        return MISPMM_OK;
+    }
     // (8 waves per workgroup -- WAVES = 8, half the iterations per wave -- was measured slower: 13.2 vs 11.6 us)
     note_kernel("bsr_mfma_bf16%s<T%d,%s>", bR == 32 ? "_b32" : "", wide ? 8 : 4, c_bf16 ? "c16" : "c32");
     if (bR == 16 && !bsr_pipe && wide) {

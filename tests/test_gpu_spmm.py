@@ -433,6 +433,44 @@ def test_bsr_bf16_mfma(oracle, n, out_bf16, block):
         assert np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
 
 
+def test_bsr_bf16_lds_staged_kernel(oracle):
+    """The opt-in LDS-staged kernel (MISPMM_BSR_LDS=1: LDS-DMA ring + transposed LDS reads) against the same oracle and
+    bound as the register-staged default (test_bsr_bf16_mfma), incl. a partial last column tile (N = 72) and bf16
+    output.  Run in a child process: the choice of kernel is read once per process."""
+    import subprocess
+    import sys
+    import tempfile
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-optimization-for-spmm_amd")
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {pkg!r})\n"
+        "from mispmm import capi, datasets, formats, ops, synth\n"
+        "csr = datasets.load_csr('ACTIVSg10K'); bsr = formats.csr_to_bsr(csr, 16); a = ops.DeviceBSR.from_host(bsr)\n"
+        "out = {}\n"
+        "for n in (128, 72, 256):\n"
+        "    b = torch.from_numpy(synth.dense_b(csr.num_cols, n)).cuda()\n"
+        "    for c16 in (0, 1):\n"
+        "        c = ops.spmm_bsr_bf16(a, ops.f32_to_bf16(a.data), ops.f32_to_bf16(b), out_bf16=bool(c16))\n"
+        "        out['%d_%d' % (n, c16)] = (ops.bf16_to_f32(c) if c16 else c).cpu().numpy()\n"
+        "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **out)\n")
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "out.npz")
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_BSR_LDS="1"), capture_output=True,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res = np.load(path)
+        assert "bsr_bf16_lds" in str(res["tag"])
+        csr = datasets.load_csr("ACTIVSg10K")
+        bsr = formats.csr_to_bsr(csr, 16)
+        a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
+        for n in (128, 72, 256):
+            b16 = synth.bf16_round(synth.dense_b(csr.num_cols, n).reshape(-1)).reshape(csr.num_cols, n)
+            ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+            scale = abs_scale(formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs, synth.bf16_round(csr.data)), b16)
+            assert np.all(np.abs(res[f"{n}_0"].astype(np.float64) - ref) <= 2e-6 * scale + 1e-30), n
+            assert np.all(np.abs(res[f"{n}_1"] - ref) <= 2 ** -8 * np.abs(ref) + 2e-6 * scale + 1e-30), n
+
+
 # --------------------------------------------------------------------------- dense helpers
 @pytest.mark.parametrize("shape", [(1, 1), (3, 130), (64, 64), (257, 65), (1000, 31)])
 def test_dense_transpose(shape):
