@@ -454,6 +454,26 @@ def run_single(args):
                 "acc_mode": other, "launch_us": round(o["median_us"], 4),
                 "roofline_frac": round(w.abytes / (o["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "reference = the reference engine's accumulate (bit-exact); fast = fp32 fma chain (<= 1e-5)"}
+        if w.fmt == "csr" and args.kernel in (0, 5):
+            # the batched entry point (mispmm_csr_batch_f32): 8 different dense operands per launch, same A.  Never
+            # `value`: the metric is one product per step; this shows what the ~1.2 us between two dependent launches
+            # costs a product of this size
+            from mispmm import ops, synth
+            nb = 8
+            bs = [w.b] + [torch.from_numpy(synth.dense_b(w.csr.num_cols, w.n, seed=1000 + i)).cuda() for i in range(1, nb)]
+            cs = [torch.empty_like(w.c) for _ in range(nb)]
+            bt = timer.measure(lambda: ops.spmm_csr_batch(w.a, bs, outs=cs, acc=args.acc, stream=stream), max(1, min(args.steps, 250)),
+                               rounds=3, precondition_s=0.01)
+            torch.cuda.synchronize()
+            per = bt["median_us"] / nb
+            same = bool(np.array_equal(cs[0].cpu().numpy(), got))
+            out["batched"] = {"operands_per_launch": nb, "us_per_product": round(per, 4), "launch_us": round(bt["median_us"], 4),
+                              "roofline_frac": round(w.abytes / (per * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "first_result_equals_single_launch": same, "kernel_tag": capi.last_kernel(),
+                              "note": "mispmm_csr_batch_f32: one launch multiplies 8 different dense operands by the same A; algorithmic "
+                                      "bytes per product against the 8 TB/s HBM peak (the operands are Infinity-Cache resident, so the "
+                                      "fraction can exceed what HBM alone would allow)"}
+            del bs, cs
         # cold single shot (SURVEY.md 8(d) asks for it next to the steady-state figure): 1 GiB is written first so
         # that neither the L2s nor the 256 MiB Infinity Cache hold A, B or C; median of 5; HIP events around ONE
         # eager launch (an empty event pair costs a few microseconds itself, reported beside it)

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "mispmm.h"
 
@@ -32,6 +33,21 @@ inline hipStream_t as_stream(mispmm_stream_t s) { return reinterpret_cast<hipStr
 
 // A launch that follows; picks up configuration errors without synchronising.
 #define MISPMM_LAUNCH_CHECK() MISPMM_HIP_TRY(hipGetLastError())
+
+// Measurement knobs (MISPMM_* environment variables that pick a kernel variant, a tiling, a depth).  The production
+// library is built WITHOUT -DMISPMM_TUNING: every knob IS its default, a constant the compiler folds, and the
+// dispatch contains no getenv.  `make tune` builds libmispmm_tune.so with the knobs live; only tools/ sweeps and the
+// tests of opt-in kernels load that one (MISPMM_LIB=.../libmispmm_tune.so).  Results never depend on a knob.
+#ifdef MISPMM_TUNING
+inline int knob_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+inline const char *knob_str(const char *name) { return getenv(name); }
+#else
+constexpr int knob_int(const char *, int dflt) { return dflt; }
+constexpr const char *knob_str(const char *) { return nullptr; }
+#endif
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }

@@ -54,14 +54,28 @@ struct EllRows {
     }
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16>
+// Batched launch (mispmm_csr_batch_f32): blockIdx.z picks one of up to kMaxBatch dense operand / result pairs, all
+// multiplied by the same A in ONE launch -- what separates two dependent launches on this chip (~1.2 us of idle
+// between the last wave of one and the first of the next: profiles/r2/stamps_default.log) is paid once per batch.
+constexpr uint32_t kMaxBatch = 16;
+struct BatchPtrs {
+    const float *b[kMaxBatch];
+    float *c[kMaxBatch];
+};
+template <bool BATCHED> struct BatchArg {};
+template <> struct BatchArg<true> {
+    BatchPtrs p;
+};
+
+template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
+          bool BATCHED = false>
 __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
     uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
-    const float *__restrict__ B, float *__restrict__ C, uint32_t c_bytes, uint32_t ldc
+    const float *__restrict__ B_one, float *__restrict__ C_one, uint32_t c_bytes, uint32_t ldc, BatchArg<BATCHED> batch
 #ifdef MISPMM_STAMPS
     , uint32_t stamp_launch  // which of the last kStampLaunches launches this is: each keeps its own stamp records
 #endif
@@ -70,6 +84,12 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     unsigned long long stamp[5];
     stamp[0] = wall_clock64();
 #endif
+    const float *__restrict__ B = B_one;
+    float *__restrict__ C = C_one;
+    if constexpr (BATCHED) {
+        B = batch.p.b[blockIdx.z];
+        C = batch.p.c[blockIdx.z];
+    }
     constexpr int GROUPS = BLOCK / G;
     constexpr int U = G < UMAX ? G : UMAX;  // B reads in flight per lane; a row of <= U entries is ONE batch
     using vec_t = typename VecOf<VEC>::type;
@@ -229,8 +249,12 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, U>([&](auto s) { consume_one(bv[decltype(s)::value], av[decltype(s)::value]); });
             } else if constexpr (SC == 16) {
-                // ragged rows: three quarters of the slots when no row of the wave reaches slot 12
-                if (!live_from(std::integral_constant<int, 12>{})) roll(std::integral_constant<int, 12>{});
+                // ragged rows: the body is as long as the longest row of the wave needs, in steps of two slots (each
+                // dropped slot still costs its broadcasts, its load issue and its sums: the general entry point ran
+                // 3.88 us on the 14-entry rows of n4c6-b13 with the 16-slot body against 3.55 us behind the uniform hint)
+                if (!live_from(std::integral_constant<int, 10>{})) roll(std::integral_constant<int, 10>{});
+                else if (!live_from(std::integral_constant<int, 12>{})) roll(std::integral_constant<int, 12>{});
+                else if (!live_from(std::integral_constant<int, 14>{})) roll(std::integral_constant<int, 14>{});
                 else roll(std::integral_constant<int, 16>{});
             } else {
                 roll(std::integral_constant<int, SC>{});
@@ -319,6 +343,9 @@ struct RowGatherArgs {
     float *C;
     uint32_t ldc;
     uint32_t mean_row_len = 0;  // nnz / M when the caller knows it (CSR, COO); 0 = unknown
+    uint32_t batch = 0;         // > 0: B / C are ignored, product i uses B_list[i] / C_list[i] (host arrays), i < batch <= kMaxBatch
+    const float *const *B_list = nullptr;
+    float *const *C_list = nullptr;
 };
 
 // P x Q XCD grid and the C store flavour.  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
@@ -335,14 +362,14 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
         uint32_t q = 0;
         int sc1 = -1;
         Env() {
-            if (const char *e = getenv("MISPMM_CSR_TILING")) {
+            if (const char *e = knob_str("MISPMM_CSR_TILING")) {
                 unsigned pp = 8, qq = 1;
                 if (sscanf(e, "%u,%u", &pp, &qq) == 2 && pp * qq == 8 && (pp == 1 || pp == 2 || pp == 4 || pp == 8)) {
                     log2p = pp == 1 ? 0 : pp == 2 ? 1 : pp == 4 ? 2 : 3;
                     q = qq;
                 }
             }
-            if (const char *e = getenv("MISPMM_STORE_SC1")) sc1 = e[0] != '0';
+            if (const char *e = knob_str("MISPMM_STORE_SC1")) sc1 = e[0] != '0';
         }
     };
     static const Env env;
@@ -381,8 +408,8 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
-    note_kernel("row_gather<G%d,V%d,%s,%s,B%d,U%d,%s,S%d> xcd %ux%u", G, VEC, acc_tag<Acc>(), rows_tag<Rows>(), BLOCK, UMAX,
-                ROLL ? "roll" : "batch", SLOTS, 1u << t.log2p, t.q);
+    note_kernel("row_gather<G%d,V%d,%s,%s,B%d,U%d,%s,S%d> xcd %ux%u%s", G, VEC, acc_tag<Acc>(), rows_tag<Rows>(), BLOCK, UMAX,
+                ROLL ? "roll" : "batch", SLOTS, 1u << t.log2p, t.q, a.batch ? " batched" : "");
 #ifdef MISPMM_STAMPS
     static uint32_t stamp_counter = 0;
     const uint32_t stamp_launch = stamp_counter++ % kStampLaunches;
@@ -390,13 +417,37 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
 #else
 #define MISPMM_STAMP_ARG
 #endif
+    if constexpr (ROLL && BLOCK == 128 && UMAX == 8 && G <= 16) {
+        if (a.batch > 0) {  // one launch for the whole batch (callers checked sc1 / c_bytes / batch <= kMaxBatch)
+            BatchArg<true> arg;
+            for (uint32_t i = 0; i < kMaxBatch; ++i) {
+                arg.p.b[i] = a.B_list[i < a.batch ? i : 0];
+                arg.p.c[i] = a.C_list[i < a.batch ? i : 0];
+            }
+            grid.z = a.batch;
+            hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS, true>), grid, dim3(BLOCK), 0, a.stream,
+                               a.M, rb_chunk, t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, nullptr, nullptr,
+                               static_cast<uint32_t>(c_bytes), a.ldc, arg MISPMM_STAMP_ARG);
+            return;
+        }
+    }
+    if (a.batch > 0) {  // this instantiation has no batched form (measurement overrides can route here): one launch each
+        for (uint32_t i = 0; i < a.batch; ++i) {
+            RowGatherArgs one = a;
+            one.batch = 0;
+            one.B = a.B_list[i];
+            one.C = a.C_list[i];
+            launch_row_gather_b<G, VEC, Acc, Rows, BLOCK, UMAX, ROLL, SLOTS>(one, rows, t);
+        }
+        return;
+    }
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
                            t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
-                           static_cast<uint32_t>(c_bytes), a.ldc MISPMM_STAMP_ARG);
+                           static_cast<uint32_t>(c_bytes), a.ldc, BatchArg<false>{} MISPMM_STAMP_ARG);
     else
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
-                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc MISPMM_STAMP_ARG);
+                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc, BatchArg<false>{} MISPMM_STAMP_ARG);
 #undef MISPMM_STAMP_ARG
 }
 
@@ -405,19 +456,19 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     // 128-thread workgroups: with 256 threads a CU holds 3.08 workgroups on the headline, so some CUs
     // carry 4 and finish late; halving the granule measured 4.49 -> 4.24 us (REFERENCE) and 4.37 -> 4.02 us
     // (FAST); 64 threads gave 4.45 / 4.10.  MISPMM_BLOCK=64|128|256 overrides (measurement aid).
-    static const int block = [] { const char *e = getenv("MISPMM_BLOCK"); return e ? atoi(e) : 128; }();
+    static const int block = knob_int("MISPMM_BLOCK", 128);
     // 8 reads in flight per lane, not 16: 74 instead of 120 VGPRs lets 6 waves per SIMD stay resident, which
     // beats finishing a 14-entry row in one batch (same box, headline: 4.25 -> 4.21 us REFERENCE, 4.43 -> 3.78 us
     // FAST; K = 256: 8.15 -> 7.59 us; K = 512: 15.5 -> 14.7 us).  MISPMM_UMAX=16 restores the deep batch.
-    static const int umax = [] { const char *e = getenv("MISPMM_UMAX"); return e ? atoi(e) : 8; }();
+    static const int umax = knob_int("MISPMM_UMAX", 8);
     // Rolling refill (G <= 16): measured on n4c6-b13, REFERENCE / FAST us: N = 128 4.06 -> 4.00 / 3.69 -> 3.70,
     // N = 256 7.01 -> 6.79 / 6.65 -> 6.23, N = 512 14.38 -> 13.96 / 14.05 -> 13.82; 12 reads in flight instead of 8
     // changed nothing.  MISPMM_ROLL=0 restores the batch-at-a-time body.
-    static const int roll = [] { const char *e = getenv("MISPMM_ROLL"); return e ? atoi(e) : 1; }();
+    static const int roll = knob_int("MISPMM_ROLL", 1);
     if constexpr ((G == 16 || G == 8) && VEC == 4 && (std::is_same_v<Rows, UniformRows> || std::is_same_v<Rows, EllRows>)) {
         // rows of 9..14 slots, all the same length (uniform CSR, or ELL of that width): no dead slots
         // (MISPMM_SLOTS=0 keeps the generic 16)
-        static const bool slots = [] { const char *e = getenv("MISPMM_SLOTS"); return !e || e[0] != '0'; }();
+        static const bool slots = knob_int("MISPMM_SLOTS", 1) != 0;
         if (roll && slots) {
             if (rows.width > 8 && rows.width <= 10) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 10>(a, rows, t);
             if (rows.width > 10 && rows.width <= 12) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 12>(a, rows, t);
@@ -430,7 +481,7 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
         // MEAN row already fills the 16-slot window (nnz >= 24 M; GL7d25: mean 29, longest 422) take 16 reads in
         // flight over 32-slot super-chunks: 116 instead of 74 VGPRs, which such short grids do not miss.
         // MISPMM_DEEP=0/1 forces the choice (measurement aid).
-        static const int deep_env = [] { const char *e = getenv("MISPMM_DEEP"); return e ? atoi(e) : -1; }();
+        static const int deep_env = knob_int("MISPMM_DEEP", -1);
         const bool deep = deep_env >= 0 ? deep_env != 0 : a.mean_row_len >= 24;
         if (roll && deep) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 16, true, 32>(a, rows, t);
     }
@@ -447,7 +498,7 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
 template <class Acc, class Rows>
 void launch_row_gather_auto(const RowGatherArgs &a, const Rows &rows, int vec) {
     const XcdTiling t = xcd_tiling(a.N, vec);
-    static const int group_env = [] { const char *e = getenv("MISPMM_GROUP"); return e ? atoi(e) : 0; }();  // measurement aid
+    static const int group_env = knob_int("MISPMM_GROUP", 0);
     // 16 or 8 lanes per row (64 or 32 columns at VEC = 4) whenever they tile the column part exactly: several
     // sub-parts per XCD part (grid.y) instead of one wide, partly idle lane group -- and the rolling body, which
     // exists for G <= 16 only (N = 96 / 192 / 384 ran 3.98 / 6.31 / 12.9 us with 32- and 64-lane groups)

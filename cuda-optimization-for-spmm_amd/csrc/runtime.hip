@@ -38,7 +38,7 @@ void note_kernel(const char *fmt, ...) {
 XcdGrid xcd_grid(uint32_t nblk) {
     // MISPMM_XCD_REMAP=0 disables the renumbering (A/B measurements only)
     static const bool enabled = [] {
-        const char *e = getenv("MISPMM_XCD_REMAP");
+        const char *e = knob_str("MISPMM_XCD_REMAP");
         return !(e && e[0] == '0');
     }();
     if (!enabled || nblk < 16) return {nblk, 0u};

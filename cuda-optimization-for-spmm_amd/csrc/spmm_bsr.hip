@@ -710,7 +710,7 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     // the 128-column kernel runs WITHOUT the register double buffer by default: 72 instead of 104 VGPRs, and the
     // extra resident waves hide the fetch latency better than the prefetch did (13.3 -> 12.2 us on config 4);
     // MISPMM_BSR_PIPE=1 restores the two-deep software pipeline (measurement aid)
-    static const bool bsr_pipe = [] { const char *e = getenv("MISPMM_BSR_PIPE"); return e && e[0] == '1'; }();
+    static const bool bsr_pipe = knob_int("MISPMM_BSR_PIPE", 0) == 1;
 #define MISPMM_BF16_PICK(KERNEL)                                                                 \
     do {                                                                                         \
         if (wide) {                                                                              \
@@ -722,14 +722,14 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     // MISPMM_BSR_LDS=1: the LDS-staged kernel (bsr_bf16_lds.hpp: LDS-DMA ring + ds_read_b64_tr_b16, the plan of round 1).
     // Passes the same parity tests as the register-staged kernel below but is SLOWER on config 4 (14.9 us at ring depth 4,
     // 15.9 at 6, 18.1 at 8, against 11.4 us; profiles/r2/bsr_bf16_variants.log), so it stays opt-in.
-    static const bool bsr_lds = [] { const char *e = getenv("MISPMM_BSR_LDS"); return e && e[0] == '1'; }();
+    static const bool bsr_lds = knob_int("MISPMM_BSR_LDS", 0) == 1;
     const uint64_t blocks_bytes = static_cast<uint64_t>(numBlocks) * 512u;
     if (bR == 16 && bsr_lds && N % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && aligned16(B) && aligned16(C) && aligned16(blocks) &&
         blocks_bytes <= 0x7FFFFFFFull) {
         const uint32_t nst = ceil_div(N, 64u);
         const XcdGrid g = xcd_grid(numBlockRows * nst);
         // ring depth 4 (3 block pairs = 15 KiB in flight per workgroup, 8 workgroups per CU); MISPMM_BSR_DEPTH=6|8 deepens it
-        static const int depth = [] { const char *e = getenv("MISPMM_BSR_DEPTH"); return e ? atoi(e) : 4; }();
+        static const int depth = knob_int("MISPMM_BSR_DEPTH", 4);
         note_kernel("bsr_bf16_lds<%s,D%d>", c_bf16 ? "c16" : "c32", depth == 4 ? 4 : depth == 6 ? 6 : 8);
 #define MISPMM_LDS_LAUNCH(CB, DD)                                                                                              \
     hipLaunchKernelGGL((bsr_bf16_lds<CB, DD>), dim3(g.grid), dim3(128), 0, as_stream(stream), numBlockRows, nst, blockRowPtrs, \

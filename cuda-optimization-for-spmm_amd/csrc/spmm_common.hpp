@@ -168,7 +168,7 @@ template <class Acc> constexpr const char *acc_tag() {
 
 // Widest vector width usable for row-major dense operands B (ldb) and C (ldc) with N columns.
 inline int pick_vec(const float *B, uint32_t ldb, const float *C, uint32_t ldc, uint32_t N) {
-    static const int cap = [] { const char *e = getenv("MISPMM_VEC"); return e ? atoi(e) : 4; }();  // measurement aid
+    static const int cap = knob_int("MISPMM_VEC", 4);
     if (cap >= 4 && N % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C)) return 4;
     if (cap >= 2 && N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && aligned8(B) && aligned8(C)) return 2;
     return 1;

@@ -526,12 +526,12 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     const bool wide = static_cast<uint64_t>(a.K) * a.ldb * 4u > 0x7FFFFFFFull;
     // kernel 5 on a matrix whose MEAN row is long (nnz >= 24 M): the deep wave-per-row kernel.  MISPMM_LONGROWS=0/1
     // forces the choice (measurement aid; results do not depend on it).
-    static const int long_env = [] { const char *e = getenv("MISPMM_LONGROWS"); return e ? atoi(e) : -1; }();
+    static const int long_env = knob_int("MISPMM_LONGROWS", -1);
     const bool long_rows = long_env >= 0 ? long_env != 0 : (a.M != 0 && a.nnz / a.M >= 24);
     if (kernel == 5 && !wide && long_rows) {
         int v = vec;
         while (v > 1 && 64u * (v / 2) >= a.N) v /= 2;
-        static const int vec_env = [] { const char *e = getenv("MISPMM_LONGROWS_VEC"); return e ? atoi(e) : 0; }();
+        static const int vec_env = knob_int("MISPMM_LONGROWS_VEC", 0);
         if (vec_env > 0) v = min(v, vec_env);
         if (v == 4) launch_wave_deep<4, Acc>(a);
         else if (v == 2) launch_wave_deep<2, Acc>(a);
@@ -610,5 +610,52 @@ extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_csr<AccRefWide>(a, kernel, vec);
     else launch_csr<AccFast>(a, kernel, vec);
     MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+// Several dense operands, one launch.  Only the row-gather kernel has a batched form; shapes it does not take
+// (a B of 2 GiB or more, rows too long for it, operands that are not 16-byte vectors) go out as one launch each.
+extern "C" int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                    const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, uint32_t batch,
+                                    const float *const *B_list_host, uint32_t N, uint32_t ldb, float *const *C_list_host,
+                                    uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_batch: unknown accumulate mode %d", acc_mode);
+    if (batch == 0 || M == 0 || N == 0) return MISPMM_OK;
+    if (!B_list_host || !C_list_host) return fail(MISPMM_ERR_INVALID_ARG, "csr_batch: null operand list");
+    if (!rowPtrs && uniformRowNnz == 0) return fail(MISPMM_ERR_INVALID_ARG, "csr_batch: rowPtrs is null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_batch: colIdxs or vals is null");
+    int vec = 4;
+    for (uint32_t i = 0; i < batch; ++i) {
+        if (int s = check_dense_args(B_list_host[i], N, ldb, C_list_host[i], ldc)) return s;
+        vec = std::min(vec, pick_vec(B_list_host[i], ldb, C_list_host[i], ldc, N));
+    }
+    const bool long_rows = uniformRowNnz == 0 && nnz / M >= 24;
+    const bool fits = static_cast<uint64_t>(K) * ldb * 4u <= 0x7FFFFFFFull && static_cast<uint64_t>(M) * ldc * 4u <= 0x7FFFFFFFull;
+    const uint32_t cpp = N / xcd_tiling(N, vec).q;
+    if (vec != 4 || !fits || long_rows || (cpp % 32 != 0)) {  // no batched kernel for this shape: one launch per operand
+        for (uint32_t i = 0; i < batch; ++i) {
+            const int st = uniformRowNnz ? mispmm_csr_uniform_f32(stream, M, K, uniformRowNnz, colIdxs, vals, B_list_host[i], N, ldb,
+                                                                 C_list_host[i], ldc, acc_mode)
+                                         : mispmm_csr_f32(stream, M, K, nnz, rowPtrs, colIdxs, vals, B_list_host[i], N, ldb,
+                                                          C_list_host[i], ldc, MISPMM_KERNEL_AUTO, acc_mode);
+            if (st != MISPMM_OK) return st;
+        }
+        return MISPMM_OK;
+    }
+    for (uint32_t first = 0; first < batch; first += kMaxBatch) {
+        RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, nullptr, N, ldb, nullptr, ldc, M ? nnz / M : 0u};
+        ga.batch = std::min(kMaxBatch, batch - first);
+        ga.B_list = B_list_host + first;
+        ga.C_list = C_list_host + first;
+        if (uniformRowNnz) {
+            if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{uniformRowNnz}, vec);
+            else launch_row_gather_auto<AccFast>(ga, UniformRows{uniformRowNnz}, vec);
+        } else {
+            if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, CsrRows{rowPtrs}, vec);
+            else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
+        }
+        MISPMM_LAUNCH_CHECK();
+    }
     return MISPMM_OK;
 }

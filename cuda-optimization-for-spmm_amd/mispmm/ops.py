@@ -145,6 +145,29 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
     return c
 
 
+def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
+    """outs[i] = A @ bs[i] for a list of equally shaped dense operands, ONE launch per 16 of them
+    (mispmm_csr_batch_f32).  Returns the list of results."""
+    if not bs:
+        return []
+    n, ldb = bs[0].shape[1], _dense_ld(bs[0])
+    for b in bs:
+        _require_gpu(b)
+        if b.shape != bs[0].shape or _dense_ld(b) != ldb:
+            raise ValueError("batched operands must share one shape and row stride")
+        if b.shape[0] != a.num_cols:
+            raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    if outs is None:
+        outs = [torch.empty((a.num_rows, n), dtype=torch.float32, device=bs[0].device) for _ in bs]
+    ldc = _dense_ld(outs[0])
+    blist = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
+    clist = (ctypes.c_void_p * len(bs))(*[c.data_ptr() for c in outs])
+    capi.check(capi.lib().mispmm_csr_batch_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),
+                                               _p(a.data), a.uniform_row_nnz, len(bs), blist, n, ldb, clist, ldc,
+                                               capi.ACC_MODES[acc]))
+    return outs
+
+
 def spmm_ell(a, b, out=None, kernel=0, acc="reference", stream=None):
     _require_gpu(a.col_idxs, b)
     if b.shape[0] != a.num_cols:

@@ -142,6 +142,17 @@ int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint3
                            const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc,
                            int acc_mode);
 
+/* Several products with the same A in ONE launch: C_list[i] = A * B_list[i], i < batch (HOST arrays of device
+ * pointers; every operand N columns wide with leading dimensions ldb / ldc).  Same arithmetic and results as
+ * `batch` calls of mispmm_csr_f32 (kernel 5) / mispmm_csr_uniform_f32 (uniformRowNnz > 0: rowPtrs may be NULL),
+ * but the time between two dependent launches -- about 1.2 us on MI355X, a third of a headline-sized product --
+ * is paid once per 16 operands.  New capability: the reference multiplies by one dense.in per process
+ * (src/main.cu:185).  Shapes the batched kernel does not take are issued as one launch each. */
+int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                         const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, uint32_t batch,
+                         const float *const *B_list_host, uint32_t N, uint32_t ldb, float *const *C_list_host, uint32_t ldc,
+                         int acc_mode);
+
 /* -------------------------------------------------------------- ELL x dense */
 /* Row-major ELL: colIdxs/vals are [M x width], padding index 0xFFFFFFFF.
  * Replaces spmmELLWrapper1/2 (src/spmm/ell/spmm_ell_k1.cu:38-63,

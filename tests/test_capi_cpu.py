@@ -156,3 +156,14 @@ def test_multi_entry_point_argument_errors():
     assert l.mispmm_multi_csr_f32(0, devs, one, bounds, 4, one, one, one, nnz, None, one, 8, 8, one, 8, 0, 0, 0, None) == capi.ERR_INVALID_ARG
     assert l.mispmm_slab_scatter(None, ctypes.c_void_p(16), 24, one, 1) == capi.ERR_INVALID_ARG  # not a 16-byte multiple
     assert l.mispmm_slab_scatter(None, ctypes.c_void_p(16), 32, one, 17) == capi.ERR_INVALID_ARG
+
+
+def test_batched_entry_point_validates_before_device_work():
+    l = capi.lib()
+    one = ctypes.c_void_p(16)
+    lst = (ctypes.c_void_p * 2)(16, 16)
+    assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 2, lst, 8, 8, lst, 8, 7) == capi.ERR_INVALID_ARG      # acc mode
+    assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 2, None, 8, 8, lst, 8, 0) == capi.ERR_INVALID_ARG     # no list
+    assert l.mispmm_csr_batch_f32(None, 4, 4, 1, None, one, one, 0, 2, lst, 8, 8, lst, 8, 0) == capi.ERR_INVALID_ARG     # no rowPtrs
+    assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 2, lst, 8, 4, lst, 8, 0) == capi.ERR_INVALID_ARG      # ldb < N
+    assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 0, lst, 8, 8, lst, 8, 0) == capi.OK                   # empty batch

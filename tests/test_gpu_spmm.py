@@ -269,6 +269,26 @@ def test_graph_replay_equals_eager(oracle):
     capi.check(l.mispmm_graph_destroy(g))
 
 
+@pytest.mark.parametrize("name,n,count", [("n4c6-b13", 128, 5), ("n4c6-b13", 128, 19), ("qh1484", 64, 3), ("delaunay_n12", 128, 16),
+                                          ("GL7d25", 64, 2), ("qh1484", 130, 3)])
+def test_csr_batched_launch_equals_single_launches(oracle, name, n, count):
+    """mispmm_csr_batch_f32: several dense operands, one launch (per 16) -- bit for bit what one call per operand gives,
+    for the uniform-row and the general CSR path, for more than 16 operands, and for shapes the batched kernel does not
+    take (long rows, a width that is not a multiple of 4: issued one by one)."""
+    csr = datasets.load_csr(name)
+    a = ops.DeviceCSR.from_host(csr)
+    bs = [dev(synth.dense_b(csr.num_cols, n, seed=100 + i)) for i in range(count)]
+    for acc in ("reference", "fast"):
+        outs = ops.spmm_csr_batch(a, bs, acc=acc)
+        torch.cuda.synchronize()
+        for i, b in enumerate(bs):
+            single = ops.spmm_csr(a, b, acc=acc)
+            assert torch.equal(outs[i], single), (name, acc, i)
+        if acc == "reference":
+            ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, bs[-1].cpu().numpy())
+            assert np.array_equal(outs[-1].cpu().numpy(), ref)
+
+
 # --------------------------------------------------------------------------- ELL / COO
 @pytest.mark.parametrize("name,ns", [("Hamrle1", [3, 32]), ("n3c5-b6", [21]), ("delaunay_n12", [128, 130]),
                                      ("n4c6-b13", [256]), ("ACTIVSg10K", [64])])
@@ -455,8 +475,11 @@ def test_bsr_bf16_lds_staged_kernel(oracle):
         "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **out)\n")
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "out.npz")
-        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_BSR_LDS="1"), capture_output=True,
-                           text=True, timeout=600)
+        # the knob is live only in the tuning build of the library (libmispmm_tune.so, -DMISPMM_TUNING)
+        tune = os.path.join(pkg, "libmispmm_tune.so")
+        assert os.path.exists(tune), "run `make -C cuda-optimization-for-spmm_amd tune`"
+        p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_BSR_LDS="1", MISPMM_LIB=tune),
+                           capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         res = np.load(path)
         assert "bsr_bf16_lds" in str(res["tag"])
