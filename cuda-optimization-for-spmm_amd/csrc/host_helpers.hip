@@ -93,3 +93,40 @@ extern "C" int mispmm_coo_sort_by_row_host(uint32_t M, uint32_t nnz, const uint3
     }
     return MISPMM_OK;
 }
+
+extern "C" int mispmm_bsr_nonzeros_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                                        const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,
+                                        const float *blocks_host, uint32_t *nnz_out, uint32_t *rowPtrs_out_host,
+                                        uint32_t *colIdxs_out_host, float *vals_out_host) {
+    if (!nnz_out) return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: nnz_out is null");
+    if (bR == 0 || bC == 0) return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: zero block dimension");
+    if (numBlockRows != 0 && !blockRowPtrs_host) return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: blockRowPtrs is null");
+    if (numBlocks != 0 && (!blockColIdxs_host || !blocks_host)) return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: null block arrays");
+    const bool fill = rowPtrs_out_host && colIdxs_out_host && vals_out_host;
+    if (!fill && (rowPtrs_out_host || colIdxs_out_host || vals_out_host))
+        return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: give all three outputs or none (size query)");
+    // row by row, blocks in storage order, columns ascending inside a block: the order in which spmmBSRCpu
+    // (spmm_bsr.cpp:17-38) adds terms into one row of C
+    uint64_t n = 0;
+    for (uint32_t R = 0; R < numBlockRows; ++R) {
+        for (uint32_t i = 0; i < bR; ++i) {
+            if (fill) rowPtrs_out_host[static_cast<size_t>(R) * bR + i] = static_cast<uint32_t>(n);
+            for (uint32_t b = blockRowPtrs_host[R]; b < blockRowPtrs_host[R + 1]; ++b) {
+                if (b >= numBlocks) return fail(MISPMM_ERR_INVALID_ARG, "bsr nonzeros: block index %u out of range", b);
+                const float *row = blocks_host + (static_cast<size_t>(b) * bR + i) * bC;
+                for (uint32_t j = 0; j < bC; ++j) {
+                    if (row[j] == 0.f) continue;  // +0 and -0 alike: the term 0 * b cannot change a finite sum
+                    if (fill) {
+                        colIdxs_out_host[n] = blockColIdxs_host[b] * bC + j;
+                        vals_out_host[n] = row[j];
+                    }
+                    ++n;
+                }
+            }
+        }
+    }
+    if (n > 0xFFFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "bsr nonzeros: more than 2^32 entries");
+    if (fill) rowPtrs_out_host[static_cast<size_t>(numBlockRows) * bR] = static_cast<uint32_t>(n);
+    *nnz_out = static_cast<uint32_t>(n);
+    return MISPMM_OK;
+}

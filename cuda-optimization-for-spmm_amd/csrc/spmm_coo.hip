@@ -190,3 +190,25 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }
+
+// The zero-skipping BSR path: the block entries that are not zero, listed per C row in the reference's order of
+// addition (mispmm_bsr_nonzeros_host), are a CSR whose REFERENCE arithmetic is COO's (fp32 product, fp32 add), so
+// it runs on the same instantiations as the prepared-bounds COO kernel above.
+extern "C" int mispmm_bsr_nonzeros_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                       const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
+                                       float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "bsr_nonzeros: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!rowPtrs) return fail(MISPMM_ERR_INVALID_ARG, "bsr_nonzeros: rowPtrs is null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "bsr_nonzeros: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsr_nonzeros: B of 2 GiB or more: use mispmm_bsr_f32");
+    const RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
+    const int vec = pick_vec(B, ldb, C, ldc, N);
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefF32>(ga, CsrRows{rowPtrs}, vec);
+    else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}

@@ -45,7 +45,8 @@ namespace cuspmm {
 // vendor cross-check: rocSPARSE has CSR and COO SpMM wired in; BSR and ELL follow the reference (none)
 CUSPMM_DEFINE_ENGINE(COO, MISPMM_COO_NUM_KERNELS, true)
 CUSPMM_DEFINE_ENGINE(ELL, MISPMM_ELL_NUM_KERNELS, false)
-CUSPMM_DEFINE_ENGINE(BSR, MISPMM_BSR_NUM_KERNELS, false)
+// BSR: kernels 1, 2 of mispmm_bsr_f32 plus kernel 3, the zero-skipping one (mispmm_bsr_nonzeros_f32)
+CUSPMM_DEFINE_ENGINE(BSR, MISPMM_BSR_NUM_KERNELS + 1, false)
 #undef CUSPMM_DEFINE_ENGINE
 
 }  // namespace cuspmm

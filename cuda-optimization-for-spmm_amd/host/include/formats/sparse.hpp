@@ -103,6 +103,12 @@ template <typename _dataT, typename _metaT> class SparseMatrixBSR : public Spars
     MT *blockColIdxs = nullptr;
     MT numBlockRows = 0;  // numRows / blockRowSize
     MT numElements = 0;   // numBlocks * blockRowSize * blockColSize
+    // device copies made by copy2Device() only (float): the block entries that are not zero, listed per row in
+    // the order spmmBSRCpu adds them -- what the zero-skipping kernel 3 multiplies from (mispmm_bsr_nonzeros_*)
+    MT *nzRowPtrs = nullptr;
+    MT *nzColIdxs = nullptr;
+    DT *nzVals = nullptr;
+    MT nzCount = 0;
 
     SparseMatrixBSR() = default;
     explicit SparseMatrixBSR(std::string filePath);

@@ -50,6 +50,9 @@ template <typename DT, typename MT> SparseMatrixBSR<DT, MT>::~SparseMatrixBSR() 
     releaseBuffer(this->blockRowPtrs, this->onDevice);
     releaseBuffer(this->blockColIdxs, this->onDevice);
     releaseBuffer(this->data, this->onDevice);
+    releaseBuffer(this->nzRowPtrs, true);
+    releaseBuffer(this->nzColIdxs, true);
+    releaseBuffer(this->nzVals, true);
 }
 
 template <typename DT, typename MT> bool SparseMatrixBSR<DT, MT>::allocateSpace(bool onDevice) {
@@ -75,7 +78,27 @@ template <typename DT, typename MT> bool SparseMatrixBSR<DT, MT>::copyData(Spars
 
 template <typename DT, typename MT> SparseMatrixBSR<DT, MT> *SparseMatrixBSR<DT, MT>::copy2Device() {
     assert(!this->onDevice && this->data != nullptr);
-    return new SparseMatrixBSR<DT, MT>(this, true);
+    auto *d = new SparseMatrixBSR<DT, MT>(this, true);
+    if constexpr (std::is_same_v<DT, float>) {
+        // once per upload: the non-zero entries in the reference's order of addition, for the zero-skipping kernel
+        uint32_t nz = 0;
+        mispmmCheckError(mispmm_bsr_nonzeros_host(this->numBlockRows, this->blockRowSize, this->blockColSize, this->numBlocks,
+                                                  this->blockRowPtrs, this->blockColIdxs, this->data, &nz, nullptr, nullptr,
+                                                  nullptr));
+        std::vector<uint32_t> rp((size_t)this->numRows + 1), ci(nz ? nz : 1);
+        std::vector<float> va(nz ? nz : 1);
+        mispmmCheckError(mispmm_bsr_nonzeros_host(this->numBlockRows, this->blockRowSize, this->blockColSize, this->numBlocks,
+                                                  this->blockRowPtrs, this->blockColIdxs, this->data, &nz, rp.data(), ci.data(),
+                                                  va.data()));
+        d->nzCount = nz;
+        d->nzRowPtrs = allocateBuffer<MT>(rp.size(), true);
+        d->nzColIdxs = allocateBuffer<MT>(ci.size(), true);
+        d->nzVals = allocateBuffer<DT>(va.size(), true);
+        copyBuffer(d->nzRowPtrs, true, rp.data(), false, rp.size() * sizeof(MT));
+        copyBuffer(d->nzColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
+        copyBuffer(d->nzVals, true, va.data(), false, va.size() * sizeof(DT));
+    }
+    return d;
 }
 
 template <typename DT, typename MT> void SparseMatrixBSR<DT, MT>::assertCheck() {

@@ -47,6 +47,16 @@ DenseMatrix<DT, MT> *spmmBSRWrapper(int kernelNum, SparseMatrixBSR<DT, MT> *a, D
                                      a->numCols * n * 4 + a->numRows * n * 4};
         // kernel 2 (fp32 MFMA) has fused numerics only; every other id follows AccT
         const int acc = kernelNum == 2 ? MISPMM_ACC_FAST : accModeOf<AccT>();
+        if (kernelNum == 3) {
+            // the zero-skipping kernel: the non-zero list built at upload (same bits as the CPU engine unless an explicit
+            // zero of A meets an Inf / NaN of B: include/mispmm.h, mispmm_bsr_nonzeros_*); flops and bytes of the list
+            const WrapperShape nzShape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->nzCount * n,
+                                       a->nzCount * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
+            return runWrapper<DT, MT>(nzShape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
+                return mispmm_bsr_nonzeros_f32(nullptr, a->numRows, a->numCols, a->nzCount, a->nzRowPtrs, a->nzColIdxs, a->nzVals,
+                                               b->data, b->numCols, b->numCols, c, ldc, acc);
+            });
+        }
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
             return mispmm_bsr_f32(nullptr, a->numBlockRows, a->numCols, a->blockRowSize, a->blockColSize, a->numBlocks,
                                   a->blockRowPtrs, a->blockColIdxs, a->data, b->data, b->numCols, b->numCols, c, ldc,

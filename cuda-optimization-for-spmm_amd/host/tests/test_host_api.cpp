@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
     EngineBSR<float, uint32_t, double> ebsr(dir);
     EngineELL<float, uint32_t, double> eell(dir);
     CHECK(ecsr.numKernels == MISPMM_CSR_NUM_KERNELS && ecsr.fmt == "CSR" && ecsr.SUPPORT_CUSPARSE);
-    CHECK(!eell.SUPPORT_CUSPARSE && ebsr.numKernels == MISPMM_BSR_NUM_KERNELS);
+    CHECK(!eell.SUPPORT_CUSPARSE && ebsr.numKernels == MISPMM_BSR_NUM_KERNELS + 1);  // + the zero-skipping kernel 3
     Dense c0(32, 32, false), c1(32, 32, false), c2(32, 32, false), c3(32, 32, false);
     CHECK(ecsr.runKernel(0, &csr, &b, &c0) == &c0);
     ecoo.runKernel(0, &coo, &b, &c1);

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mispmm_ell_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_ell_colmajor_to_rowmajor_host": (_i, [_u32, _u32, _u32, _vp, _vp, _c.POINTER(_u32), _vp, _vp]),
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
+    "mispmm_bsr_nonzeros_host": (_i, [_u32, _u32, _u32, _u32, _vp, _vp, _vp, _c.POINTER(_u32), _vp, _vp, _vp]),
+    "mispmm_bsr_nonzeros_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_coo_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _i, _i]),
     "mispmm_coo_row_bounds": (_i, [_vp, _u32, _u32, _vp, _vp]),

@@ -193,6 +193,38 @@ def spmm_bsr(a, b, out=None, kernel=0, acc="reference", stream=None):
     return c
 
 
+def bsr_nonzeros(bsr, device="cuda"):
+    """The non-zero block entries of a host BSR as a DeviceCSR in the reference's order of addition
+    (mispmm_bsr_nonzeros_host) -- the once-per-upload analysis step of the zero-skipping BSR path."""
+    l = capi.lib()
+    ptrs = np.ascontiguousarray(bsr.block_row_ptrs, dtype=np.uint32)
+    cols = np.ascontiguousarray(bsr.block_col_idxs, dtype=np.uint32)
+    data = np.ascontiguousarray(bsr.data, dtype=np.float32).reshape(-1)
+    nnz = ctypes.c_uint32(0)
+    args = (bsr.num_block_rows, bsr.block_row_size, bsr.block_col_size, bsr.num_blocks, ptrs.ctypes.data, cols.ctypes.data,
+            data.ctypes.data, ctypes.byref(nnz))
+    capi.check(l.mispmm_bsr_nonzeros_host(*args, None, None, None))
+    rp = np.empty(bsr.num_rows + 1, dtype=np.uint32)
+    ci = np.empty(max(1, nnz.value), dtype=np.uint32)
+    va = np.empty(max(1, nnz.value), dtype=np.float32)
+    capi.check(l.mispmm_bsr_nonzeros_host(*args, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+    return DeviceCSR(bsr.num_rows, bsr.num_cols, nnz.value, _dev_u32(rp, device), _dev_u32(ci[:nnz.value], device),
+                     _dev_f32(va[:nnz.value], device), 0)
+
+
+def spmm_bsr_nonzeros(nz, b, out=None, acc="reference", stream=None):
+    """C = A @ B from the non-zero list of a BSR (bsr_nonzeros): fp32 product, fp32 add in the reference's order."""
+    _require_gpu(nz.row_ptrs, b)
+    if b.shape[0] != nz.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {nz.num_cols} columns")
+    n = b.shape[1]
+    c = _out(nz.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_bsr_nonzeros_f32(_stream_ptr(stream), nz.num_rows, nz.num_cols, nz.nnz, _p(nz.row_ptrs),
+                                                  _p(nz.col_idxs), _p(nz.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
+                                                  capi.ACC_MODES[acc]))
+    return c
+
+
 def coo_row_bounds(a, stream=None):
     """The (M+1)-entry row-boundary array of a row-sorted device COO (the once-per-upload analysis step)."""
     _require_gpu(a.row_idxs)

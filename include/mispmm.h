@@ -185,6 +185,22 @@ int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, ui
                    int acc_mode);
 #define MISPMM_BSR_NUM_KERNELS 2
 
+/* Zero-skipping BSR.  At BSR-16 the SuiteSparse matrices of data/ are ~98 % explicit zeros (ACTIVSg10K: 33 100 blocks
+ * for 137 736 non-zeros): the dense block arithmetic of mispmm_bsr_f32 kernel 1 spends 84 us where the non-zeros
+ * need 7.  The host helper lists the block entries that are not zero as (rowPtrs[M+1], colIdxs, vals), per C row in
+ * the order spmmBSRCpu adds them (blocks in storage order, ascending column inside a block, spmm_bsr.cpp:17-38): call
+ * it with the three outputs NULL for *nnz_out, then with arrays of that size, once per upload.  The device call
+ * multiplies from that list; REFERENCE = fp32 product, fp32 add in list order.
+ * NUMERICS: identical bits to spmmBSRCpu whenever no explicit zero of A meets an Inf or NaN of B -- a skipped term
+ * 0 * b adds +-0, which never changes a sum that started at +0; but 0 * Inf = NaN, which the reference (and kernel 1)
+ * propagate and this path does not.  That is why it is a separate entry point and not the default. */
+int mispmm_bsr_nonzeros_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                             const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host, const float *blocks_host,
+                             uint32_t *nnz_out, uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host, float *vals_out_host);
+int mispmm_bsr_nonzeros_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                            const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
+                            uint32_t ldc, int acc_mode);
+
 /* bf16 blocks and B (raw bf16 bit patterns), fp32 accumulate on
  * v_mfma_f32_16x16x32_bf16; bR = bC = 16 (two blocks per instruction) or 32.  C is fp32 (c_bf16 = 0) or bf16.
  * New capability (BASELINE.json config 4); the reference has no bf16 path. */

@@ -167,3 +167,22 @@ def test_batched_entry_point_validates_before_device_work():
     assert l.mispmm_csr_batch_f32(None, 4, 4, 1, None, one, one, 0, 2, lst, 8, 8, lst, 8, 0) == capi.ERR_INVALID_ARG     # no rowPtrs
     assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 2, lst, 8, 4, lst, 8, 0) == capi.ERR_INVALID_ARG      # ldb < N
     assert l.mispmm_csr_batch_f32(None, 4, 4, 1, one, one, one, 0, 0, lst, 8, 8, lst, 8, 0) == capi.OK                   # empty batch
+
+
+def test_bsr_nonzero_list_is_in_the_reference_order_of_addition():
+    """mispmm_bsr_nonzeros_host: per row, blocks in storage order and ascending column inside a block; zeros dropped."""
+    csr = datasets.load_csr("Hamrle1")
+    bsr = formats.csr_to_bsr(csr, 4)
+    l = capi.lib()
+    ptrs, cols = bsr.block_row_ptrs.astype(np.uint32), bsr.block_col_idxs.astype(np.uint32)
+    data = np.ascontiguousarray(bsr.data, dtype=np.float32).reshape(-1)
+    nnz = ctypes.c_uint32(0)
+    head = (bsr.num_block_rows, 4, 4, bsr.num_blocks, ptrs.ctypes.data, cols.ctypes.data, data.ctypes.data, ctypes.byref(nnz))
+    capi.check(l.mispmm_bsr_nonzeros_host(*head, None, None, None))
+    assert nnz.value == csr.nnz
+    rp, ci, va = np.empty(bsr.num_rows + 1, np.uint32), np.empty(nnz.value, np.uint32), np.empty(nnz.value, np.float32)
+    capi.check(l.mispmm_bsr_nonzeros_host(*head, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+    # blocks of this converter are column-sorted, so the list must equal the CSR itself
+    assert np.array_equal(rp, csr.row_ptrs) and np.array_equal(ci, csr.col_idxs) and np.array_equal(va, csr.data)
+    assert l.mispmm_bsr_nonzeros_host(*head, rp.ctypes.data, None, None) == capi.ERR_INVALID_ARG
+    assert l.mispmm_bsr_nonzeros_f32(None, 4, 4, 1, None, None, None, None, 8, 8, None, 8, 0) == capi.ERR_INVALID_ARG

@@ -106,7 +106,7 @@ def test_host_api_gpu(golden_dir):
 @pytest.mark.parametrize("d", ["small_32x32_generated", "small_210_generated"])
 def test_cli_full_engine_flow_on_gpu(golden_dir, d):
     g = os.path.join(golden_dir, d)
-    expected_kernels = {"CSR": ["0", "1", "2", "3", "4", "5", "-1"], "COO": ["0", "1", "2", "-1"], "BSR": ["0", "1", "2"],
+    expected_kernels = {"CSR": ["0", "1", "2", "3", "4", "5", "-1"], "COO": ["0", "1", "2", "-1"], "BSR": ["0", "1", "2", "3"],
                         "ELL": ["0", "1"]}
     p = run_cli("--csr", "--coo", "--bsr", "--ell", "--iters", "20", "-d", g)
     recs = records(p.stdout)
@@ -118,7 +118,7 @@ def test_cli_full_engine_flow_on_gpu(golden_dir, d):
         got = [r["kernelType"] for r in by_fmt[fmt]]
         if fmt == "BSR":                      # 1x1 blocks: the MFMA kernel declines and reports zeros
             assert got == kernels and by_fmt[fmt][2]["correct"] == "0" and by_fmt[fmt][2]["cudaKernelTimeMs"] == "0.000000"
-            checked = by_fmt[fmt][:2]
+            checked = by_fmt[fmt][:2] + by_fmt[fmt][3:]          # kernel 3 = the zero-skipping one
         else:
             assert got == kernels, (fmt, got)
             checked = by_fmt[fmt]
@@ -200,11 +200,11 @@ def test_cli_vendor_check_for_bsr(tmp_path):
     formats.write_bsr(d / "qh1484.bsr", formats.csr_to_bsr(csr, 4))
     p = run_cli("--bsr", "--vendor-bsr", "-k", "64", "-d", str(d))
     recs = [r for r, _ in records(p.stdout)]
-    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "-1"]
-    assert recs[1]["correct"] == "1" and recs[3]["correct"] == "1", [(r["kernelType"], r["correct"]) for r in recs]
+    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "3", "-1"]
+    assert recs[1]["correct"] == "1" and recs[3]["correct"] == "1" and recs[4]["correct"] == "1", [(r["kernelType"], r["correct"]) for r in recs]
     # without the flag the BSR engine reports what the reference's does: no vendor record
     p = run_cli("--bsr", "-k", "64", "-d", str(d))
-    assert [r["kernelType"] for r, _ in records(p.stdout)] == ["0", "1", "2"]
+    assert [r["kernelType"] for r, _ in records(p.stdout)] == ["0", "1", "2", "3"]
 
 
 def test_validate_tool_checks_cli_dumps(tmp_path, golden_dir):

@@ -453,6 +453,38 @@ def test_bsr_bf16_mfma(oracle, n, out_bf16, block):
         assert np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
 
 
+@pytest.mark.parametrize("name,block,n", [("ACTIVSg10K", 16, 128), ("qh1484", 4, 64), ("Hamrle1", 2, 32), ("dw1024", 32, 40)])
+def test_bsr_zero_skipping_path(oracle, name, block, n):
+    """mispmm_bsr_nonzeros_*: the block entries that are not zero, multiplied in the reference's order of addition --
+    bit for bit spmmBSRCpu for finite operands (a skipped 0 * b only ever adds +-0)."""
+    csr = datasets.load_csr(name)
+    bsr = formats.csr_to_bsr(csr, block)
+    nz = ops.bsr_nonzeros(bsr)
+    assert nz.nnz == int(np.count_nonzero(bsr.data))
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_bsr(bsr.num_rows, block, block, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, b)
+    assert np.array_equal(ops.spmm_bsr_nonzeros(nz, dev(b)).cpu().numpy(), ref)
+    assert np.array_equal(ops.spmm_bsr(ops.DeviceBSR.from_host(bsr), dev(b), kernel=1).cpu().numpy(), ref)
+    assert_fast_close(ops.spmm_bsr_nonzeros(nz, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+
+
+def test_bsr_zero_skipping_differs_only_where_a_zero_meets_a_nonfinite(oracle):
+    """The documented difference: 0 * Inf = NaN in the reference's dense block arithmetic (and in kernel 1); the
+    zero-skipping path never forms that product.  Everywhere else the two agree bit for bit."""
+    csr = datasets.load_csr("Hamrle1")
+    bsr = formats.csr_to_bsr(csr, 4)
+    b = synth.dense_b(csr.num_cols, 16)
+    b[5, 3] = np.inf
+    ref = oracle.spmm_bsr(bsr.num_rows, 4, 4, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, b)
+    dense = ops.spmm_bsr(ops.DeviceBSR.from_host(bsr), dev(b), kernel=1).cpu().numpy()
+    assert np.array_equal(dense, ref, equal_nan=True)
+    skip = ops.spmm_bsr_nonzeros(ops.bsr_nonzeros(bsr), dev(b)).cpu().numpy()
+    differs = ~((skip == ref) | (np.isnan(skip) & np.isnan(ref)))
+    assert differs.any() and np.all(np.isnan(ref[differs])) and np.all(differs[:, [c for c in range(16) if c != 3]] == False)  # noqa: E712
+    touched = np.abs(csr.to_dense()[:, 5]) > 0            # rows with a true non-zero in column 5 get the Inf either way
+    assert np.all(np.isinf(skip[touched, 3]) | np.isnan(skip[touched, 3]))
+
+
 def test_bsr_bf16_lds_staged_kernel(oracle):
     """The opt-in LDS-staged kernel (MISPMM_BSR_LDS=1: LDS-DMA ring + transposed LDS reads) against the same oracle and
     bound as the register-staged default (test_bsr_bf16_mfma), incl. a partial last column tile (N = 72) and bf16

@@ -89,6 +89,11 @@ def main():
         us = timed(lambda: ops.spmm_bsr(a, b, out=c, kernel=kernel, acc=acc, stream=s), s)
         report(f"4a: large_20000 BSR-16 K=128 fp32 kernel {kernel}", us, useful, datasets.bsr_algorithmic_bytes(bsr, 128),
                acc=acc, executed_TFLOPs=round(executed / us / 1e6, 2))
+    nz = ops.bsr_nonzeros(bsr)
+    for acc in ("reference", "fast"):
+        us = timed(lambda: ops.spmm_bsr_nonzeros(nz, b, out=c, acc=acc, stream=s), s)
+        report("4a: large_20000 BSR-16 K=128 fp32 kernel 3 (zero-skipping, non-zero list)", us, useful,
+               nz.nnz * 8 + (csr.num_rows + 1) * 4 + csr.num_cols * 128 * 4 + csr.num_rows * 128 * 4, acc=acc)
     blocks16, b16 = ops.f32_to_bf16(a.data), ops.f32_to_bf16(b)
     for out_bf16 in (False, True):
         c16 = torch.empty((csr.num_rows, 128), dtype=torch.int16 if out_bf16 else torch.float32, device="cuda")
