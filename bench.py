@@ -185,6 +185,7 @@ class BsrBf16Workload(Workload):
         self.bsr = formats.csr_to_bsr(self.csr, block)
         self.b_host = synth.dense_b(self.csr.num_cols, n)
         self.a = ops.DeviceBSR.from_host(self.bsr)
+        self.bsrc = ops.DeviceBSRC.from_host(self.bsr)       # once-per-upload analysis: occupied columns per block row
         self.blocks16 = ops.f32_to_bf16(self.a.data)
         self.b16 = ops.f32_to_bf16(torch.from_numpy(self.b_host).cuda())
         self.c = torch.empty((self.csr.num_rows, n), dtype=torch.float32, device="cuda")
@@ -195,12 +196,17 @@ class BsrBf16Workload(Workload):
         self.abytes = datasets.bsr_algorithmic_bytes(self.bsr, n, elem=2, out_elem=4)
         self.workload = (f"{matrix} BSR block {block} {self.csr.num_rows}x{self.csr.num_cols} "
                          f"{self.bsr.num_blocks} blocks (nnz {self.csr.nnz}) x dense K={n} bf16, C fp32")
-        self.extra_config = {"block_dim": block, "blocks": int(self.bsr.num_blocks)}
+        self.extra_config = {"block_dim": block, "blocks": int(self.bsr.num_blocks), "mfma_k_steps": int(self.bsrc.num_steps),
+                             "bsr_kernel": "column-compacted block rows (mispmm_bsrc_bf16)" if args.kernel != 1
+                             else "one B panel per block (mispmm_bsr_bf16)"}
         self.has_fast = False
 
-    def step(self, stream, acc=None):
+    def step(self, stream, acc=None, dense_blocks=None):
         from mispmm import ops
-        ops.spmm_bsr_bf16(self.a, self.blocks16, self.b16, out_bf16=False, out=self.c, stream=stream)
+        if (self.args.kernel == 1) if dense_blocks is None else dense_blocks:
+            ops.spmm_bsr_bf16(self.a, self.blocks16, self.b16, out_bf16=False, out=self.c, stream=stream)
+        else:
+            ops.spmm_bsrc_bf16(self.bsrc, self.b16, out_bf16=False, out=self.c, stream=stream)
 
     def host_result(self):
         return self.c.cpu().numpy()
@@ -437,9 +443,18 @@ def run_single(args):
                              "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src)},
     }
     if w.fmt == "bsr":
-        ex = w.executed_flops / (launch_us * 1e-6) / 1e12
+        executed = w.executed_flops if args.kernel == 1 else 2.0 * w.bsrc.num_steps * 16 * 32 * w.n
+        ex = executed / (launch_us * 1e-6) / 1e12
         out["mfma"] = {"executed_TFLOPs": round(ex, 2), "dense_bf16_peak_frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4),
-                       "note": "dense block products on a 1.6 % filled BSR; `value` counts the useful flops (2*nnz*K)"}
+                       "note": "MFMA flops actually executed (K steps x 16 x 32 x N x 2); `value` counts the useful flops (2*nnz*K)"}
+    if not args.no_extras and w.fmt == "bsr":
+        o = timer.measure(lambda: w.step(stream, dense_blocks=args.kernel != 1), min(args.steps, 500), rounds=3, precondition_s=0.01)
+        out["other_bsr_kernel"] = {"kernel_tag": capi.last_kernel(), "launch_us": round(o["median_us"], 4),
+                                   "roofline_frac": round(w.abytes / (o["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "note": "--kernel 1 = one B panel per 16x16 block (mispmm_bsr_bf16), default = column-compacted "
+                                           "block rows (mispmm_bsrc_bf16); both v_mfma_f32_16x16x32_bf16"}
+        w.step(stream)
+        torch.cuda.synchronize()
     if not args.no_extras:
         if args.launch == "graph" and args.steps < MIN_GRAPH_NODES:
             g = timer.measure(step, args.steps, rounds=3, precondition_s=0.01, min_nodes=1)

@@ -1,5 +1,6 @@
 // Host-only entry points of the C ABI (no device work): format conversion and row sharding.
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "mispmm_internal.hpp"
@@ -128,5 +129,69 @@ extern "C" int mispmm_bsr_nonzeros_host(uint32_t numBlockRows, uint32_t bR, uint
     if (n > 0xFFFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "bsr nonzeros: more than 2^32 entries");
     if (fill) rowPtrs_out_host[static_cast<size_t>(numBlockRows) * bR] = static_cast<uint32_t>(n);
     *nnz_out = static_cast<uint32_t>(n);
+    return MISPMM_OK;
+}
+
+namespace {
+// fp32 -> bf16 bit pattern, round to nearest even; a NaN stays a (quiet) NaN
+inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return static_cast<uint16_t>((u >> 16) | 0x0040u);
+    return static_cast<uint16_t>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+}  // namespace
+
+extern "C" int mispmm_bsr_compact_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                                            const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,
+                                            const float *blocks_host, uint32_t *nSteps_out, uint32_t *stepPtrs_out_host,
+                                            uint32_t *cols_out_host, uint16_t *tiles_out_host) {
+    if (!nSteps_out) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: nSteps_out is null");
+    if (bR != 16 || bC == 0) return fail(MISPMM_ERR_UNSUPPORTED, "bsr compact: block rows of 16 only (got %u x %u blocks)", bR, bC);
+    if (numBlockRows != 0 && !blockRowPtrs_host) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: blockRowPtrs is null");
+    if (numBlocks != 0 && (!blockColIdxs_host || !blocks_host)) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: null block arrays");
+    const bool fill = stepPtrs_out_host && cols_out_host && tiles_out_host;
+    if (!fill && (stepPtrs_out_host || cols_out_host || tiles_out_host))
+        return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: give all three outputs or none (size query)");
+    uint64_t steps = 0;
+    std::vector<uint32_t> cols;
+    for (uint32_t R = 0; R < numBlockRows; ++R) {
+        // columns of this block row that hold a value which is still non-zero as bf16, in the order the blocks store
+        // them (= ascending when block columns ascend): the k order of the MFMA steps
+        cols.clear();
+        for (uint32_t b = blockRowPtrs_host[R]; b < blockRowPtrs_host[R + 1]; ++b) {
+            if (b >= numBlocks) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: block index %u out of range", b);
+            const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
+            for (uint32_t j = 0; j < bC; ++j) {
+                bool any = false;
+                for (uint32_t i = 0; i < 16 && !any; ++i) any = (bf16_rne(blk[static_cast<size_t>(i) * bC + j]) & 0x7FFFu) != 0;
+                if (any) cols.push_back(b * bC + j);  // (block, column-in-block) for now
+            }
+        }
+        const uint32_t nsteps = static_cast<uint32_t>((cols.size() + 31) / 32);
+        if (fill) {
+            stepPtrs_out_host[R] = static_cast<uint32_t>(steps);
+            for (uint32_t s = 0; s < nsteps; ++s) {
+                uint32_t *cdst = cols_out_host + (steps + s) * 32;
+                uint16_t *tdst = tiles_out_host + (steps + s) * 512;
+                for (uint32_t k = 0; k < 32; ++k) {
+                    const size_t e = static_cast<size_t>(s) * 32 + k;
+                    if (e < cols.size()) {
+                        const uint32_t b = cols[e] / bC, j = cols[e] % bC;
+                        cdst[k] = blockColIdxs_host[b] * bC + j;
+                        const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
+                        for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = bf16_rne(blk[static_cast<size_t>(i) * bC + j]);
+                    } else {
+                        cdst[k] = 0xFFFFFFFFu;  // padding: a dropped B-row read, zero coefficients
+                        for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = 0;
+                    }
+                }
+            }
+        }
+        steps += nsteps;
+    }
+    if (steps > 0x03FFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "bsr compact: too many K steps");
+    if (fill) stepPtrs_out_host[numBlockRows] = static_cast<uint32_t>(steps);
+    *nSteps_out = static_cast<uint32_t>(steps);
     return MISPMM_OK;
 }

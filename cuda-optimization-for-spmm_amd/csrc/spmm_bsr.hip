@@ -444,6 +444,114 @@ __global__ __launch_bounds__(64 * WAVES, PIPE ? 1 : (WAVES == 4 ? 5 : 4)) void b
     }
 }
 
+// ------------------------------------------------------------------------------- bsrc_mfma_bf16
+// Column-compacted block rows (mispmm_bsr_compact_bf16_host): at 16 x 16 the SuiteSparse matrices of data/ fill their
+// blocks to ~2 % (ACTIVSg10K: 26.5 blocks = 424 block columns per block row, of which 71 hold a non-zero), so the
+// dense-block kernel above gathers a 16-row B panel for every block: 135 MB through the vector L1s for 5 MB of B.
+// Here a block row is its list of occupied columns, padded to a multiple of 32, and its values gathered to those
+// columns as [16 rows][32 k] bf16 tiles: one v_mfma_f32_16x16x32_bf16 K step per 32 occupied columns (2.7 steps per
+// block row instead of 13.2 block pairs), each B row fetched by its own index.  One WAVE owns a (block row, 128
+// output columns) item: no cross-wave reduction, no LDS, no barrier; a two-deep register pipeline keeps the next
+// step's 8 B-row reads (16 bytes per lane each) and its A tile in flight while this step's eight tiles are multiplied.
+// Lane (c, g): A operand row c, k 8g .. 8g+7 of the step; B operand rows cols[8g .. 8g+7], its TPL = 8 interleaved
+// output columns 8c .. 8c+7 (tile t <-> column 8c + t), regrouped per tile with v_perm_b32 as in bsr_mfma_bf16.
+// Terms of an output element are summed in ascending k = storage order of the occupied columns; deterministic.
+template <bool C_BF16>
+__global__ __launch_bounds__(256) void bsrc_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ stepPtrs,
+                                                      const uint32_t *__restrict__ cols, const uint16_t *__restrict__ tiles,
+                                                      const uint16_t *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                                      void *__restrict__ Cv, uint32_t ldc, uint32_t xcd_chunk) {
+    constexpr int TPL = 8;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t item = xcd_block(blockIdx.x, xcd_chunk) * 4 + wave;
+    if (item >= Mb * nST) return;  // wave-uniform; no barrier in this kernel
+    const uint32_t R = item / nST, st = item - R * nST;
+    const uint32_t c = lane & 15, g = lane >> 4;
+    const uint32_t ncol = st * (16 * TPL) + c * TPL;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
+    const uint32_t ldb2 = ldb * 2u;
+
+    f32x4_t acc[TPL];
+#pragma unroll
+    for (int t = 0; t < TPL; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const uint32_t s0 = stepPtrs[R], s1 = stepPtrs[R + 1];
+
+    struct Step {
+        u32x4_t araw;
+        uint32_t braw[8][TPL / 2];
+    };
+    auto load_idx = [&](uint32_t s, u32x4_t &lo, u32x4_t &hi) {  // this lane's 8 B-row indices of step s
+        const u32x4_t *p = reinterpret_cast<const u32x4_t *>(cols + static_cast<size_t>(s) * 32u + g * 8u);
+        lo = p[0];
+        hi = p[1];
+    };
+    auto load_step = [&](uint32_t s, const u32x4_t &lo, const u32x4_t &hi, Step &f) {
+        f.araw = *reinterpret_cast<const u32x4_t *>(tiles + static_cast<size_t>(s) * 512u + c * 32u + g * 8u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t col = e < 4 ? lo[e] : hi[e - 4];
+            // padding (0xFFFFFFFF) and lanes past N: a dropped read (zeros); the coefficients there are zero as well
+            const uint32_t voff = col == 0xFFFFFFFFu ? kDropLoad : col * ldb2 + lane_off;
+            const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) f.braw[e][w] = r[w];
+        }
+    };
+    auto multiply = [&](const Step &f) {
+        const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, f.araw);
+#pragma unroll
+        for (int w = 0; w < TPL / 2; ++w) {
+            u32x4_t even, odd;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t lo = f.braw[2 * p][w], hi = f.braw[2 * p + 1][w];
+                even[p] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
+                odd[p] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);   // {hi.h1, lo.h1}
+            }
+            acc[2 * w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, even), acc[2 * w], 0, 0, 0);
+            acc[2 * w + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, odd), acc[2 * w + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (s0 < s1) {
+        const uint32_t last = s1 - 1;
+        u32x4_t ilo, ihi, nlo, nhi;
+        load_idx(s0, ilo, ihi);
+        load_idx(min(s0 + 1, last), nlo, nhi);
+        Step cur;
+        load_step(s0, ilo, ihi, cur);
+        for (uint32_t s = s0; s < s1; ++s) {
+            Step nxt;
+            const bool more = s + 1 < s1;  // wave-uniform
+            if (more) load_step(s + 1, nlo, nhi, nxt);
+            load_idx(min(s + 2, last), nlo, nhi);
+            multiply(cur);
+            if (more) cur = nxt;
+        }
+    }
+    if (ncol < N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t crow = static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol;
+            if constexpr (C_BF16) {
+                using bf2 = __bf16 __attribute__((ext_vector_type(2)));
+                uint32_t o[TPL / 2];
+#pragma unroll
+                for (int w = 0; w < TPL / 2; ++w)
+                    o[w] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(acc[2 * w][r]), static_cast<__bf16>(acc[2 * w + 1][r])});
+                *reinterpret_cast<u32x4_t *>(static_cast<uint16_t *>(Cv) + crow) = u32x4_t{o[0], o[1], o[2], o[3]};
+            } else {
+                float *dst = static_cast<float *>(Cv) + crow;
+#pragma unroll
+                for (int w = 0; w < TPL / 4; ++w)
+                    *reinterpret_cast<f32x4_t *>(dst + 4 * w) = f32x4_t{acc[4 * w][r], acc[4 * w + 1][r], acc[4 * w + 2][r], acc[4 * w + 3][r]};
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- bsr_mfma_bf16_b32
 // 32 x 32 blocks: a block's 32 columns are exactly the K = 32 of one v_mfma_f32_16x16x32_bf16, so no
 // pairing; its 32 rows are two 16-row halves that share the B fragment (one B fetch, two MFMAs per
@@ -754,6 +862,30 @@ extern "C" int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, ui
     else MISPMM_BF16_PICK(bsr_mfma_bf16_b32);
 #undef MISPMM_BF16_PICK
 #undef MISPMM_BF16_LAUNCH
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+extern "C" int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t nSteps, const uint32_t *stepPtrs,
+                                const uint32_t *cols, const uint16_t *tiles, const uint16_t *B, uint32_t N, uint32_t ldb, void *C,
+                                uint32_t ldc, int c_bf16) {
+    if (numBlockRows == 0 || N == 0) return MISPMM_OK;
+    if (!stepPtrs || !B || !C) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_bf16: null pointer");
+    if (nSteps != 0 && (!cols || !tiles)) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_bf16: null step arrays");
+    if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_bf16: leading dimension smaller than N");
+    if (N % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || !aligned16(B) || !aligned16(C) || !aligned16(tiles) || !aligned16(cols) ||
+        static_cast<uint64_t>(K) * ldb * 2u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsrc_bf16: N / ldb / ldc must be multiples of 8, operands 16-byte aligned, B below 2 GiB");
+    const uint32_t nST = ceil_div(N, 128u);
+    const XcdGrid xg = xcd_grid(ceil_div(numBlockRows * nST, 4u));
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
+    note_kernel("bsrc_mfma_bf16<%s>", c_bf16 ? "c16" : "c32");
+    if (c_bf16)
+        hipLaunchKernelGGL((bsrc_mfma_bf16<true>), dim3(xg.grid), dim3(256), 0, as_stream(stream), numBlockRows, nST, stepPtrs, cols, tiles,
+                           B, b_bytes, N, ldb, C, ldc, xg.chunk);
+    else
+        hipLaunchKernelGGL((bsrc_mfma_bf16<false>), dim3(xg.grid), dim3(256), 0, as_stream(stream), numBlockRows, nST, stepPtrs, cols, tiles,
+                           B, b_bytes, N, ldb, C, ldc, xg.chunk);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

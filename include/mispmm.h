@@ -209,6 +209,23 @@ int mispmm_bsr_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, u
                     const uint16_t *blocks, const uint16_t *B, uint32_t N, uint32_t ldb, void *C, uint32_t ldc,
                     int c_bf16);
 
+/* Column-compacted block rows for the bf16 MFMA path.  A 16-row block row touches few of the columns its blocks span
+ * (ACTIVSg10K at 16 x 16: 71 of 424 on average), so instead of one B panel per block it keeps, per block row, the
+ * list of columns that hold a non-zero (padded with 0xFFFFFFFF to a multiple of 32) and its values gathered to those
+ * columns as bf16 tiles [16 rows][32 k]: one v_mfma_f32_16x16x32_bf16 step per 32 occupied columns.
+ * HOST helper (once per upload; bR must be 16, values rounded to bf16 RNE here): outputs NULL = size query for
+ * *nSteps_out; then stepPtrs[numBlockRows + 1], cols[nSteps * 32], tiles[nSteps * 512] (raw bf16 bits).
+ * Device call: B and C as for mispmm_bsr_bf16 (bf16 bits; C fp32 or bf16), N / ldb / ldc multiples of 8.
+ * Same results as mispmm_bsr_bf16 up to the order of the fp32 sums; like the zero-skipping fp32 path it never forms
+ * 0 * b for columns a block row does not occupy.  New capability (BASELINE.json config 4); the reference has no bf16. */
+int mispmm_bsr_compact_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                                 const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host, const float *blocks_host,
+                                 uint32_t *nSteps_out, uint32_t *stepPtrs_out_host, uint32_t *cols_out_host,
+                                 uint16_t *tiles_out_host);
+int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t nSteps, const uint32_t *stepPtrs,
+                     const uint32_t *cols, const uint16_t *tiles, const uint16_t *B, uint32_t N, uint32_t ldb, void *C, uint32_t ldc,
+                     int c_bf16);
+
 /* -------------------------------------------------------------- COO x dense */
 /* Row-major-sorted COO (the order convert_mtx.py:172-190 writes).  PRECONDITION: rowIdxs is
  * non-decreasing -- an unsorted array makes the row boundaries meaningless and the kernel read out of

@@ -485,6 +485,70 @@ def test_bsr_zero_skipping_differs_only_where_a_zero_meets_a_nonfinite(oracle):
     assert np.all(np.isinf(skip[touched, 3]) | np.isnan(skip[touched, 3]))
 
 
+@pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (256, True), (8, False)])
+def test_bsrc_bf16_column_compacted_block_rows(oracle, n, out_bf16):
+    """mispmm_bsrc_bf16 (BASELINE config 4's default kernel): per block row the occupied columns and the values gathered
+    to them as 16 x 32 bf16 tiles, one MFMA step per 32 columns.  Same oracle and bound as the dense-block kernel."""
+    csr = datasets.load_csr("ACTIVSg10K")
+    bsr = formats.csr_to_bsr(csr, 16)
+    a = ops.DeviceBSRC.from_host(bsr)
+    nzmask = synth.bf16_round(csr.data) != 0       # the matrix stores a few explicit zeros: those columns are not occupied
+    occupied = sum(len(np.unique(csr.col_idxs[csr.row_ptrs[r]:csr.row_ptrs[r + 16]][nzmask[csr.row_ptrs[r]:csr.row_ptrs[r + 16]]]))
+                   for r in range(0, csr.num_rows, 16))
+    assert int((a.cols.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum()) == occupied
+    b = synth.dense_b(csr.num_cols, n)
+    a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    c = ops.spmm_bsrc_bf16(a, ops.f32_to_bf16(dev(b)), out_bf16=out_bf16)
+    got = (ops.bf16_to_f32(c) if out_bf16 else c).cpu().numpy()
+    scale = abs_scale(formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs, synth.bf16_round(csr.data)), b16)
+    if out_bf16:
+        assert np.all(np.abs(got - ref) <= 2 ** -8 * np.abs(ref) + 2e-6 * scale + 1e-30)
+    else:
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+    again = ops.spmm_bsrc_bf16(a, ops.f32_to_bf16(dev(b)), out_bf16=out_bf16)
+    assert torch.equal(c, again)                                     # deterministic
+
+
+def test_bsrc_bf16_small_and_ragged_block_rows(oracle):
+    """Block rows with 0, 1 and more than 32 occupied columns, rectangular 16 x 8 blocks, a width that is refused."""
+    rng = np.random.default_rng(11)
+    mb, kb, bc = 9, 40, 8
+    ptrs, idxs, blocks = [0], [], []
+    for r in range(mb):
+        cnt = [0, 1, 12, 3, 0, 7, 25, 2, 5][r]
+        cols = np.sort(rng.choice(kb, size=cnt, replace=False))
+        idxs += list(cols)
+        for _ in range(cnt):
+            blk = np.where(rng.random((16, bc)) < 0.3, rng.uniform(-2, 2, (16, bc)), 0.0).astype(np.float32)
+            blocks.append(blk)
+        ptrs.append(len(idxs))
+    data = np.stack(blocks) if blocks else np.zeros((0, 16, bc), np.float32)
+    bsr = formats.BSR(mb * 16, kb * bc, int(data.size), 16, bc, np.array(ptrs, np.uint32), np.array(idxs, np.uint32), data)
+    n = 64
+    b = synth.dense_b(kb * bc, n)
+    a16 = synth.bf16_round(data.reshape(-1)).reshape(data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    ref = oracle.spmm_bsr(mb * 16, 16, bc, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    c = ops.spmm_bsrc_bf16(ops.DeviceBSRC.from_host(bsr), ops.f32_to_bf16(dev(b))).cpu().numpy()
+    scale = np.abs(bsr_to_dense(bsr, a16)).astype(np.float64) @ np.abs(b16).astype(np.float64)
+    assert np.all(np.abs(c.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+    assert np.all(c[4 * 16:5 * 16] == 0)                             # an empty block row is overwritten with zeros
+    with pytest.raises(capi.MispmmError):
+        ops.spmm_bsrc_bf16(ops.DeviceBSRC.from_host(bsr), ops.f32_to_bf16(dev(synth.dense_b(kb * bc, 12))))
+
+
+def bsr_to_dense(bsr, data):
+    d = np.zeros((bsr.num_rows, bsr.num_cols), dtype=np.float32)
+    br, bc = bsr.block_row_size, bsr.block_col_size
+    for r in range(bsr.num_rows // br):
+        for k in range(int(bsr.block_row_ptrs[r]), int(bsr.block_row_ptrs[r + 1])):
+            cidx = int(bsr.block_col_idxs[k])
+            d[r * br:(r + 1) * br, cidx * bc:(cidx + 1) * bc] = data[k]
+    return d
+
+
 def test_bsr_bf16_lds_staged_kernel(oracle):
     """The opt-in LDS-staged kernel (MISPMM_BSR_LDS=1: LDS-DMA ring + transposed LDS reads) against the same oracle and
     bound as the register-staged default (test_bsr_bf16_mfma), incl. a partial last column tile (N = 72) and bf16
