@@ -66,8 +66,9 @@ def parse():
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
     p.add_argument("--bucket", type=int, default=16, help="N>1: steps per C-slab exchange")
-    p.add_argument("--exchange", default="both", choices=["allgather", "peer", "both"],
-                   help="N>1: how C slabs travel; `both` measures the two and reports the faster as `value`")
+    p.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "both"],
+                   help="N>1: how C slabs travel (default: RCCL all-gather); `peer` = direct stores into IPC-mapped peer "
+                        "buffers, `both` measures the two and reports the faster as `value`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the other accumulate mode and the cold single shot (profiling passes use this)")

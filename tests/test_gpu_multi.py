@@ -107,7 +107,7 @@ def _bench(*args, env=None):
 
 
 def test_bench_distributed_path_single_rank_over_rccl():
-    line = _bench("--gpus", "1", "--steps", "40", "--warmup", "8", "--bucket", "8", env={"MISPMM_FORCE_DIST": "1"})
+    line = _bench("--gpus", "1", "--steps", "40", "--warmup", "8", "--bucket", "8", "--exchange", "both", env={"MISPMM_FORCE_DIST": "1"})
     assert line["n_gpus"] == 1 and set(line["exchange_modes"]) == {"allgather", "peer"}
     assert all("value" in v for v in line["exchange_modes"].values()), line["exchange_modes"]
 
