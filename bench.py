@@ -52,6 +52,17 @@ TIMED_S = 0.02                   # minimum length of one timed round
 ROUNDS = 5
 MIN_GRAPH_NODES = 1000           # launches per captured graph (the K steps are captured ceil(1000 / K) times over)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+_REAL_STDOUT = None
+
+
+def emit(obj):
+    """The one JSON line of the contract, on the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def parse():
@@ -65,7 +76,7 @@ def parse():
     p.add_argument("--kernel", type=int, default=0, help="kernel id of the format's entry point (0 = library default)")
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
-    p.add_argument("--bucket", type=int, default=16, help="N>1: steps per C-slab exchange")
+    p.add_argument("--bucket", type=int, default=0, help="N>1: steps per C-slab exchange and per bucket hipGraph (0 = 64)")
     p.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "both"],
                    help="N>1: how C slabs travel (default: RCCL all-gather); `peer` = direct stores into IPC-mapped peer "
                         "buffers, `both` measures the two and reports the faster as `value`")
@@ -516,7 +527,7 @@ def run_single(args):
                                    "note": "one eager launch after a 1 GiB cache flush, HIP events, median of 5 (not the metric)"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, got, args.acc)
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ------------------------------------------------------------------------------------------ N > 1
@@ -547,6 +558,7 @@ def run_multi(args):
     cfg_matrix = args.matrix or "n4c6-b13"
     n = args.k_cols or (512 if args.config == "5" else 128)
     csr = datasets.load_csr(cfg_matrix)
+    bucket = args.bucket if args.bucket > 0 else 64
     modes = ["allgather", "peer"] if args.exchange == "both" else [args.exchange]
     if shared_gpu:
         modes = [m for m in modes if m == "peer"] or ["peer"]
@@ -556,8 +568,7 @@ def run_multi(args):
     results, whole = {}, None
     for mode in modes:
         try:
-            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=args.bucket,
-                                       exchange=mode)
+            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode)
         except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
             results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
             job = None
@@ -572,26 +583,28 @@ def run_multi(args):
         job.broadcast_b(b_host)                      # one-time, outside the timed region
         job.run(args.warmup)
         job.finish()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        job.run(args.steps)
-        job.finish()
-        torch.cuda.synchronize()
-        dist.barrier()
-        wall = time.perf_counter() - t0
+
+        def timed(total_steps, gather):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.run(total_steps, gather=gather)
+            job.finish(gather=gather)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank uses the same (slowest) figure
+            return float(t[0])
+
+        # as at N = 1: the K steps are repeated until the timed region lasts >= 20 ms (a single pass of a small K times
+        # the launch latency of one bucket graph and one collective, not a step); `replays` says how often
+        est = timed(args.steps, True)
+        replays = max(1, int(np.ceil(TIMED_S / max(est, 1e-6))))
+        unit = bucket // int(np.gcd(args.steps, bucket))       # replays that make K * R a whole number of buckets
+        replays = -(-replays // unit) * unit
+        wall = timed(args.steps * replays, True) / replays
         # the same steps with C left row-sharded (no exchange): the kernel-only figure
-        dist.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        job.run(args.steps, gather=False)
-        job.finish(gather=False)
-        torch.cuda.synchronize()
-        dist.barrier()
-        compute_s = time.perf_counter() - t1
-        t = torch.tensor([wall, compute_s], dtype=torch.float64, device="cpu" if shared_gpu else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, compute_s = float(t[0]), float(t[1])
+        compute_s = timed(args.steps * replays, False) / replays
         # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
         job.run(1)
         job.finish()
@@ -603,7 +616,8 @@ def run_multi(args):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok[0]) == 0.0:
             raise SystemExit(f"bench: exchanged C ({mode}) differs from the unsharded product -- refusing to report a number")
-        results[mode] = {"value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
+        results[mode] = {"replays": replays,
+                         "value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
                          "kernel_only_value": round(flops * args.steps / compute_s / 1e9, 2),
                          "kernel_only_ms_per_step": round(compute_s * 1e3 / args.steps, 6)}
         job.close()
@@ -621,7 +635,7 @@ def run_multi(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": f"SuiteSparse {cfg_matrix} (reference data/{label}) x seeded synthetic B",
             "config": {"workload": f"{cfg_matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
-                       "parallelism": f"row-sharded x{world}, B replicated, C slabs exchanged every {args.bucket} steps "
+                       "parallelism": f"row-sharded x{world}, B replicated, C slabs exchanged every {bucket} steps "
                                       f"({best}: " + ("RCCL all_gather_into_tensor" if best == "allgather" else
                                                       "direct copies into IPC-mapped peer buffers over xGMI") + ")",
                        "kernel": args.kernel, "acc_mode": args.acc,
@@ -635,7 +649,7 @@ def run_multi(args):
                          "frac": round(abytes / (r["kernel_only_ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                          "traffic": None, "note": "kernel-only time against the N-GPU aggregate HBM peak"},
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -657,13 +671,19 @@ def spawn_ranks(args):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, out)
     sys.exit(rc)
 
 
 def main():
     args = parse()
+    # libraries print banners on stdout (RCCL its version block, gloo its connection summary): the contract is ONE JSON
+    # line there, so everything but that line goes to stderr -- fd 1 is pointed at stderr and the line is written to the
+    # saved descriptor at the end
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force = os.environ.get("MISPMM_FORCE_DIST") == "1"    # rehearse the distributed path with a single rank
     if args.gpus > 1 and world == 1 and not force:
