@@ -141,6 +141,13 @@ struct AccRefWide {
         acc[2] += static_cast<double>(p23[0]);
         acc[3] += static_cast<double>(p23[1]);
     }
+    // two terms: one packed multiply (same IEEE rounding per element), two widening adds
+    static __device__ __forceinline__ void mac2(T *acc, float a, float b0, float b1) {
+        using f2 = float __attribute__((ext_vector_type(2)));
+        const f2 p = f2{a, a} * f2{b0, b1};
+        acc[0] += static_cast<double>(p[0]);
+        acc[1] += static_cast<double>(p[1]);
+    }
 };
 
 // Reference COO / ELL / BSR: fp32 product then fp32 add (e.g. spmm_ell.cpp:25).

@@ -388,7 +388,11 @@ __global__ __launch_bounds__(256) void csr_wave_deep(uint32_t M, const uint32_t 
 
     for (uint32_t base = start; base < end; base += PHASE) {
         const uint32_t n = min(static_cast<uint32_t>(PHASE), end - base);
-        const uint32_t nblk = (n + 7u) / 8u;
+        // padded to whole RINGS of NBLK blocks (W slots): every pass of the loop below then consumes and refills exactly
+        // W slots with no branch in between, which is what lets the compiler count its vmcnt waits -- with a per-block
+        // `if (blk < nblk)` it fell back to vmcnt(7..0) before every block, i.e. a full drain of the window per 8
+        // entries (GL7d25: 19.7 us; the padding slots are dropped loads with a zero coefficient: exact no-ops)
+        const uint32_t nblk = ((n + W - 1u) / W) * NBLK;
         for (uint32_t i = lane; i < nblk * 8u; i += 64) {
             u2 pair{kDropLoad, 0u};
             if (i < n) {
@@ -421,32 +425,32 @@ __global__ __launch_bounds__(256) void csr_wave_deep(uint32_t M, const uint32_t 
                 if constexpr (VEC == 4 && std::is_same_v<Acc, AccRefWide>) {
                     Acc::mac4(acc, av[R * 8 + t], vec_get<VEC>(bv[R * 8 + t], 0), vec_get<VEC>(bv[R * 8 + t], 1),
                               vec_get<VEC>(bv[R * 8 + t], 2), vec_get<VEC>(bv[R * 8 + t], 3));
+                } else if constexpr (VEC == 2 && std::is_same_v<Acc, AccRefWide>) {
+                    Acc::mac2(acc, av[R * 8 + t], vec_get<VEC>(bv[R * 8 + t], 0), vec_get<VEC>(bv[R * 8 + t], 1));
                 } else {
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) Acc::mac(acc[v], av[R * 8 + t], vec_get<VEC>(bv[R * 8 + t], v));
                 }
             }
         };
-        static_for<0, NBLK>([&](auto r) {
-            if (static_cast<uint32_t>(decltype(r)::value) < nblk) issue_block(decltype(r)::value, r);
-        });
-        for (uint32_t b0 = 0; b0 < nblk; b0 += NBLK) {
+        auto pin = [&] {
+            // a refill reuses the registers just consumed: keep it behind the sums (see row_gather.hpp)
+            if constexpr (VEC == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+            else if constexpr (VEC == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
+            else asm volatile("" : "+v"(acc[0]) : : "memory");
+        };
+        static_for<0, NBLK>([&](auto r) { issue_block(decltype(r)::value, r); });  // nblk >= NBLK: the first ring
+        uint32_t b0 = 0;
+        for (; b0 + NBLK < nblk; b0 += NBLK) {  // steady state: W reads in flight, each block refilled as it is consumed
             static_for<0, NBLK>([&](auto r) {
-                const uint32_t blk = b0 + decltype(r)::value;
-                if (blk < nblk) {  // wave-uniform
-                    consume_block(r);
-                    if (blk + NBLK < nblk) {
-                        // the refill reuses the registers just consumed: keep it behind the sums (see row_gather.hpp)
-                        if constexpr (VEC == 4) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
-                        else if constexpr (VEC == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]) : : "memory");
-                        else asm volatile("" : "+v"(acc[0]) : : "memory");
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_block(blk + NBLK, r);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                consume_block(r);
+                pin();
+                __builtin_amdgcn_sched_barrier(0);
+                issue_block(b0 + NBLK + decltype(r)::value, r);
+                __builtin_amdgcn_sched_barrier(0);
             });
         }
+        static_for<0, NBLK>([&](auto r) { consume_block(r); });  // the last ring drains
         // the next phase overwrites the strip: every read of this phase has been issued and, LDS being in order per
         // wave, completes before those writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -528,7 +532,9 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     // forces the choice (measurement aid; results do not depend on it).
     static const int long_env = knob_int("MISPMM_LONGROWS", -1);
     const bool long_rows = long_env >= 0 ? long_env != 0 : (a.M != 0 && a.nnz / a.M >= 24);
-    if (kernel == 5 && !wide && long_rows) {
+    // ... up to 256 output columns: from 384 on the lane-group kernel with 16 reads in flight is faster again (GL7d25,
+    // REFERENCE us, deep wave / lane group: N = 128 17.2 / 22.9, 256 26.2 / 29.1, 384 39.4 / 37.4, 512 44.5 / 30.2)
+    if (kernel == 5 && !wide && long_rows && (long_env == 1 || a.N < 384)) {
         int v = vec;
         while (v > 1 && 64u * (v / 2) >= a.N) v /= 2;
         static const int vec_env = knob_int("MISPMM_LONGROWS_VEC", 0);
