@@ -560,8 +560,6 @@ def run_multi(args):
     csr = datasets.load_csr(cfg_matrix)
     bucket = args.bucket if args.bucket > 0 else 64
     modes = ["allgather", "peer"] if args.exchange == "both" else [args.exchange]
-    if shared_gpu:
-        modes = [m for m in modes if m == "peer"] or ["peer"]
     b_host = synth.dense_b(csr.num_cols, n) if rank == 0 else None
     flops = datasets.spmm_flops(csr.nnz, n)
     abytes = datasets.csr_algorithmic_bytes(csr, n)
