@@ -42,6 +42,10 @@ namespace cuspmm {
         }                                                                                                         \
     };
 
+// `--dtype bf16`: the BSR product on the bf16 MFMA kernels (host operands a, b and their device copies), two records
+template <typename DT, typename MT>
+void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *db);
+
 // vendor cross-check: rocSPARSE has CSR and COO SpMM wired in; BSR and ELL follow the reference (none)
 CUSPMM_DEFINE_ENGINE(COO, MISPMM_COO_NUM_KERNELS, true)
 CUSPMM_DEFINE_ENGINE(ELL, MISPMM_ELL_NUM_KERNELS, false)

@@ -25,6 +25,7 @@ struct WrapperShape {
     uint32_t rows, cols, nnz;  // of A, as the record prints them
     double flops;              // 2 * (useful non-zeros) * N
     double algorithmicBytes;   // compulsory traffic of one SpMM
+    const char *dtype = nullptr;  // printed with the record when the kernel's arithmetic type is not DT
 };
 
 // launch(cData, ldc) enqueues one SpMM into the device buffer and returns a mispmm status.

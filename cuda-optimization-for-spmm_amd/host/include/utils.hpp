@@ -27,6 +27,7 @@ struct SteadyStats {
     double hbmGBps = 0;      // algorithmic bytes / time
     double rooflineFrac = 0; // hbmGBps / 8000 (MI355X HBM3E peak; times ngpus for a sharded run)
     int ngpus = 0;           // > 0: the record is a row-sharded multi-GPU run over this many devices
+    const char *dtype = nullptr;  // set when the kernel did not compute in the engine's DT (e.g. "bf16")
 };
 
 // `ordering`: 0 = ROW_MAJOR.  `kernelNum`: 0 = sequential CPU engine, -1 = vendor library.

@@ -42,6 +42,11 @@ void runEngine(EngT *engine, typename EngT::MataT *a, typename EngT::MatbT *b, f
         if (!savePath.empty() && last != nullptr) last->save2File(savePath);
         delete last;
 
+        // 3a. `--dtype bf16`: the bf16 MFMA kernels for BSR (BASELINE config 4; the reference has no bf16)
+        if constexpr (std::is_same_v<ma_t, SparseMatrixBSR<typename ma_t::DT, typename ma_t::MT>>) {
+            if (engineOptions().bf16) spmmBSRBf16<typename ma_t::DT, typename ma_t::MT>(a, da, b, db);
+        }
+
         // 3b. `--gpus n`: the same product row-sharded over n devices (CSR; new capability, src/main.cu:176 pins one)
         if constexpr (std::is_same_v<ma_t, SparseMatrixCSR<typename ma_t::DT, typename ma_t::MT>>) {
             if (engineOptions().gpus > 0)

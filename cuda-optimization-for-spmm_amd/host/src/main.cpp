@@ -11,6 +11,7 @@
 //   --vendor-bsr     also run the rocSPARSE cross-check for --bsr (square blocks; the reference builds the BSR
 //                    descriptor, sparse_bsr.cu:138-160, but never enables the check: engine_bsr.hpp:24)
 //   --save <file>    write the last result matrix as text
+//   --dtype <t>      fp32 (default) | bf16: with --bsr and 16-row blocks also run the bf16 MFMA kernels (BASELINE config 4)
 //   --gpus <n>       (--csr) also run the product row-sharded over n GPUs of this node: B replicated, C row slabs
 //                    gathered over xGMI; --gather first|peer|rccl|none picks how (default first = into device 0)
 #include <getopt.h>
@@ -39,6 +40,7 @@ static void printHelp(const char *prog) {
               << "  --no-vendor     Skip the rocSPARSE cross-check\n"
               << "  --vendor-bsr    rocSPARSE cross-check for --bsr as well (square blocks)\n"
               << "  --save <file>   Save the last result matrix\n"
+              << "  --dtype <t>     fp32 | bf16 (with --bsr, 16-row blocks: bf16 MFMA kernels as well)\n"
               << "  --gpus <n>      With --csr: also run row-sharded over n GPUs (B replicated, C slabs gathered)\n"
               << "  --gather <how>  first | peer | rccl | none (default first: slabs copied into device 0)\n"
               << "  -h, --help      Display this help message\n";
@@ -49,7 +51,7 @@ int main(int argc, char *argv[]) {
     bool wantCoo = false, wantCsr = false, wantBsr = false, wantEll = false, cpuOnly = false, vendorBsr = false;
     int device = 0;
     long synthCols = 0;
-    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE, OPT_VENDORBSR, OPT_GPUS, OPT_GATHER };
+    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE, OPT_VENDORBSR, OPT_GPUS, OPT_GATHER, OPT_DTYPE };
     const option longOpts[] = {{"bsr", no_argument, nullptr, 'B'},           {"coo", no_argument, nullptr, 'O'},
                                {"csr", no_argument, nullptr, 'S'},           {"ell", no_argument, nullptr, 'E'},
                                {"cuda", no_argument, nullptr, 'U'},          {"help", no_argument, nullptr, 'h'},
@@ -63,6 +65,7 @@ int main(int argc, char *argv[]) {
                                {"vendor-bsr", no_argument, nullptr, OPT_VENDORBSR},
                                {"gpus", required_argument, nullptr, OPT_GPUS},
                                {"gather", required_argument, nullptr, OPT_GATHER},
+                               {"dtype", required_argument, nullptr, OPT_DTYPE},
                                {nullptr, 0, nullptr, 0}};
     int opt;
     while ((opt = getopt_long(argc, argv, "hd:k:", longOpts, nullptr)) != -1) {
@@ -86,6 +89,15 @@ int main(int argc, char *argv[]) {
             case OPT_NOVENDOR: cuspmm::engineOptions().vendorCheck = false; break;
             case OPT_SAVE: savePath = optarg; break;
             case OPT_VENDORBSR: vendorBsr = true; break;
+            case OPT_DTYPE: {
+                const std::string t = optarg;
+                if (t == "bf16") cuspmm::engineOptions().bf16 = true;
+                else if (t != "fp32") {
+                    std::cerr << "Error: --dtype takes fp32 | bf16\n";
+                    return EXIT_FAILURE;
+                }
+                break;
+            }
             case OPT_GPUS: cuspmm::engineOptions().gpus = std::atoi(optarg); break;
             case OPT_GATHER: {
                 const std::string g = optarg;

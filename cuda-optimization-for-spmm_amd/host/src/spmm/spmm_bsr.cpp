@@ -2,6 +2,9 @@
 #include "engine/engine_bsr.hpp"
 #include "engine/wrapper_common.hpp"
 
+#include <cstring>
+#include <vector>
+
 namespace cuspmm {
 
 // Kernel 0: block rows, then blocks in storage order, then block element (i, j), each adding
@@ -64,6 +67,84 @@ DenseMatrix<DT, MT> *spmmBSRWrapper(int kernelNum, SparseMatrixBSR<DT, MT> *a, D
         });
     }
 }
+
+namespace {
+// fp32 -> bf16 -> fp32, round to nearest even (finite values; a NaN stays a NaN)
+inline float bf16Round(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) u |= 0x00400000u;
+    else u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+    float r;
+    std::memcpy(&r, &u, 4);
+    return r;
+}
+}  // namespace
+
+// `--dtype bf16` (BASELINE.json config 4; the reference has no bf16): A and B rounded to bf16, fp32 accumulate on
+// v_mfma_f32_16x16x32_bf16.  The self-check reference is the sequential engine run on the ROUNDED operands, so
+// `correct` judges the kernels' arithmetic and not the rounding of the inputs.  Two records with "dtype":"bf16":
+// kernelType 4 = column-compacted block rows (mispmm_bsrc_bf16), 5 = one B panel per block (mispmm_bsr_bf16).
+template <typename DT, typename MT>
+void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *db) {
+    if constexpr (!std::is_same_v<DT, float>) {
+        throw std::runtime_error("Not implemented");
+    } else {
+        assert(!a->onDevice && da->onDevice && !b->onDevice && db->onDevice);
+        if (a->blockRowSize != 16) throw std::runtime_error("--dtype bf16 needs 16-row blocks (got " + std::to_string(a->blockRowSize) + ")");
+        b->toOrdering(ORDERING::ROW_MAJOR);
+        db->toOrdering(ORDERING::ROW_MAJOR);
+        const uint32_t N = b->numCols, K = a->numCols;
+        // sequential engine on the rounded operands
+        SparseMatrixBSR<DT, MT> ar(a, false);
+        for (size_t i = 0; i < ar.numElements; ++i) ar.data[i] = bf16Round(ar.data[i]);
+        DenseMatrix<DT, MT> br(b, false);
+        for (size_t i = 0; i < br.numElements(); ++i) br.data[i] = bf16Round(br.data[i]);
+        DenseMatrix<DT, MT> ref(a->numRows, N, false, ORDERING::ROW_MAJOR);
+        spmmBSRCpu<DT, MT, double>(&ar, &br, &ref);
+        // device operands: bf16 bits of the blocks and of B, the compacted block rows
+        uint16_t *blocks16 = allocateBuffer<uint16_t>(a->numElements ? a->numElements : 1, true);
+        uint16_t *b16 = allocateBuffer<uint16_t>((size_t)K * N, true);
+        mispmmCheckError(mispmm_f32_to_bf16(nullptr, a->numElements, da->data, blocks16));
+        mispmmCheckError(mispmm_f32_to_bf16(nullptr, (size_t)K * N, db->data, b16));
+        uint32_t nSteps = 0;
+        mispmmCheckError(mispmm_bsr_compact_bf16_host(a->numBlockRows, a->blockRowSize, a->blockColSize, a->numBlocks, a->blockRowPtrs,
+                                                      a->blockColIdxs, a->data, &nSteps, nullptr, nullptr, nullptr));
+        std::vector<uint32_t> sp((size_t)a->numBlockRows + 1), cl((size_t)(nSteps ? nSteps : 1) * 32);
+        std::vector<uint16_t> tl((size_t)(nSteps ? nSteps : 1) * 512);
+        mispmmCheckError(mispmm_bsr_compact_bf16_host(a->numBlockRows, a->blockRowSize, a->blockColSize, a->numBlocks, a->blockRowPtrs,
+                                                      a->blockColIdxs, a->data, &nSteps, sp.data(), cl.data(), tl.data()));
+        uint32_t *dsp = allocateBuffer<uint32_t>(sp.size(), true), *dcl = allocateBuffer<uint32_t>(cl.size(), true);
+        uint16_t *dtl = allocateBuffer<uint16_t>(tl.size(), true);
+        copyBuffer(dsp, true, sp.data(), false, sp.size() * 4);
+        copyBuffer(dcl, true, cl.data(), false, cl.size() * 4);
+        copyBuffer(dtl, true, tl.data(), false, tl.size() * 2);
+        const double n = N;
+        WrapperShape shape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * da->nzCount * n,
+                           a->numElements * 2.0 + a->numBlocks * 4.0 + (a->numBlockRows + 1.0) * 4 + a->numCols * n * 2 + a->numRows * n * 4};
+        shape.dtype = "bf16";
+        delete runWrapper<DT, MT>(shape, 4, db, &ref, [&](float *c, uint32_t ldc) {
+            return mispmm_bsrc_bf16(nullptr, a->numBlockRows, K, nSteps, dsp, dcl, dtl, b16, N, N, c, ldc, 0);
+        });
+        if (a->blockColSize == 16) {
+            delete runWrapper<DT, MT>(shape, 5, db, &ref, [&](float *c, uint32_t ldc) {
+                return mispmm_bsr_bf16(nullptr, a->numBlockRows, K, 16, 16, a->numBlocks, da->blockRowPtrs, da->blockColIdxs, blocks16, b16,
+                                       N, N, c, ldc, 0);
+            });
+        }
+        releaseBuffer(blocks16, true);
+        releaseBuffer(b16, true);
+        releaseBuffer(dsp, true);
+        releaseBuffer(dcl, true);
+        releaseBuffer(dtl, true);
+    }
+}
+
+template void spmmBSRBf16<float, uint32_t>(SparseMatrixBSR<float, uint32_t> *, SparseMatrixBSR<float, uint32_t> *,
+                                           DenseMatrix<float, uint32_t> *, DenseMatrix<float, uint32_t> *);
+template void spmmBSRBf16<double, uint32_t>(SparseMatrixBSR<double, uint32_t> *, SparseMatrixBSR<double, uint32_t> *,
+                                            DenseMatrix<double, uint32_t> *, DenseMatrix<double, uint32_t> *);
 
 #define CUSPMM_INST(DT)                                                                                              \
     template DenseMatrix<DT, uint32_t> *spmmBSRCpu<DT, uint32_t, double>(SparseMatrixBSR<DT, uint32_t> *,           \

@@ -35,6 +35,7 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
     delete res;
 
     SteadyStats steady;
+    steady.dtype = shape.dtype;
     const int iters = engineOptions().steadyIters;
     if (iters > 0) {
         mispmm_event_t e0 = nullptr, e1 = nullptr;

@@ -26,6 +26,7 @@ void reportTime(const std::string &tc, uint32_t aNumRows, uint32_t aNumCols, uin
                     steady->iters, steady->usPerSpmm, steady->gflops, steady->hbmGBps, steady->rooflineFrac);
     }
     if (steady && steady->ngpus > 0) std::printf(",\n\"ngpus\":\"%d\"", steady->ngpus);
+    if (steady && steady->dtype) std::printf(",\n\"dtype\":\"%s\"", steady->dtype);
     std::printf("\n},\n");
     std::fflush(stdout);
 }
@@ -68,6 +69,7 @@ template <typename T> T *allocateBuffer(size_t count, bool onDevice) {
 template float *allocateBuffer<float>(size_t, bool);
 template double *allocateBuffer<double>(size_t, bool);
 template uint32_t *allocateBuffer<uint32_t>(size_t, bool);
+template uint16_t *allocateBuffer<uint16_t>(size_t, bool);
 
 void releaseBuffer(void *ptr, bool onDevice) {
     if (!ptr) return;

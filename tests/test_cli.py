@@ -249,3 +249,21 @@ def test_cli_row_sharded_run_behind_the_gpus_flag(tmp_path):
         assert [r["kernelType"] for r in recs if "ngpus" not in r] == ["0", "1", "2", "3", "4", "5"]
     p = run_cli("--csr", "-k", "8", "--gpus", "99", "-d", str(d), check=False)
     assert p.returncode != 0 and "--gpus 99" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_bf16_block_products_behind_the_dtype_flag(tmp_path):
+    """`cuspmm --bsr --dtype bf16` (BASELINE config 4 through the CLI): the two bf16 MFMA kernels run after the fp32 ones,
+    are checked against the sequential engine on bf16-rounded operands, and their records carry "dtype":"bf16"."""
+    from mispmm import datasets, formats
+    d = tmp_path / "medium_2048"
+    d.mkdir()
+    formats.write_bsr(d / "dw1024.bsr", formats.csr_to_bsr(datasets.load_csr("dw1024", dtype=np.float64), 16))
+    p = run_cli("--bsr", "--dtype", "bf16", "-k", "128", "--iters", "20", "-d", str(d))
+    recs = [r for r, _ in records(p.stdout)]
+    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "3", "4", "5"]
+    assert all(r["correct"] == "1" for r in recs), [(r["kernelType"], r["correct"]) for r in recs]
+    assert [r.get("dtype") for r in recs] == [None, None, None, None, "bf16", "bf16"]
+    assert float(recs[4]["gflops"]) > 0 and float(recs[5]["gflops"]) > 0
+    p = run_cli("--bsr", "--dtype", "fp8", "-d", str(d), check=False)
+    assert p.returncode != 0 and "--dtype" in p.stderr
