@@ -28,9 +28,10 @@ struct WrapperShape {
     const char *dtype = nullptr;  // printed with the record when the kernel's arithmetic type is not DT
 };
 
-// launch(cData, ldc) enqueues one SpMM into the device buffer and returns a mispmm status.
+// launch(cData, ldc, stream) enqueues one SpMM into the device buffer on `stream` (NULL = the default stream, as the
+// reference launches) and returns a mispmm status.
 template <typename DT, typename MT>
 DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref,
-                                const std::function<int(DT *, uint32_t)> &launch);
+                                const std::function<int(DT *, uint32_t, mispmm_stream_t)> &launch);
 
 }  // namespace cuspmm

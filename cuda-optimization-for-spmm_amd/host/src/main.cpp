@@ -4,7 +4,7 @@
 //   --device <n>     GPU ordinal (default 0; the reference hard-codes 7)
 //   -k <cols>        use a seeded synthetic dense operand with <cols> columns instead of dense.in
 //   --synth <mode>   uniform (default) | exact
-//   --iters <n>      also time n back-to-back launches per kernel: GFLOP/s, GB/s, roofline fraction
+//   --iters <n>      also time n back-to-back launches per kernel, replayed from a hipGraph: GFLOP/s, GB/s, roofline fraction
 //   --acc <mode>     reference | fast   (default: from the engine's AccT = double -> reference)
 //   --cpu-only       run only the sequential CPU engine (no GPU needed)
 //   --no-vendor      skip the rocSPARSE cross-check
@@ -34,7 +34,7 @@ static void printHelp(const char *prog) {
               << "  --device <n>    GPU ordinal (default 0)\n"
               << "  -k <cols>       Synthetic dense operand with <cols> columns instead of dense.in\n"
               << "  --synth <mode>  uniform | exact\n"
-              << "  --iters <n>     Steady-state timing iterations per kernel\n"
+              << "  --iters <n>     Steady-state timing: n launches per kernel replayed from a hipGraph\n"
               << "  --acc <mode>    reference | fast\n"
               << "  --cpu-only      Sequential CPU engine only\n"
               << "  --no-vendor     Skip the rocSPARSE cross-check\n"

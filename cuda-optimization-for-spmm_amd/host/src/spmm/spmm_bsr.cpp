@@ -55,13 +55,13 @@ DenseMatrix<DT, MT> *spmmBSRWrapper(int kernelNum, SparseMatrixBSR<DT, MT> *a, D
             // zero of A meets an Inf / NaN of B: include/mispmm.h, mispmm_bsr_nonzeros_*); flops and bytes of the list
             const WrapperShape nzShape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->nzCount * n,
                                        a->nzCount * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
-            return runWrapper<DT, MT>(nzShape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
-                return mispmm_bsr_nonzeros_f32(nullptr, a->numRows, a->numCols, a->nzCount, a->nzRowPtrs, a->nzColIdxs, a->nzVals,
+            return runWrapper<DT, MT>(nzShape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+                return mispmm_bsr_nonzeros_f32(stream, a->numRows, a->numCols, a->nzCount, a->nzRowPtrs, a->nzColIdxs, a->nzVals,
                                                b->data, b->numCols, b->numCols, c, ldc, acc);
             });
         }
-        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
-            return mispmm_bsr_f32(nullptr, a->numBlockRows, a->numCols, a->blockRowSize, a->blockColSize, a->numBlocks,
+        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            return mispmm_bsr_f32(stream, a->numBlockRows, a->numCols, a->blockRowSize, a->blockColSize, a->numBlocks,
                                   a->blockRowPtrs, a->blockColIdxs, a->data, b->data, b->numCols, b->numCols, c, ldc,
                                   kernelNum, acc);
         });
@@ -124,12 +124,12 @@ void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseM
         WrapperShape shape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * da->nzCount * n,
                            a->numElements * 2.0 + a->numBlocks * 4.0 + (a->numBlockRows + 1.0) * 4 + a->numCols * n * 2 + a->numRows * n * 4};
         shape.dtype = "bf16";
-        delete runWrapper<DT, MT>(shape, 4, db, &ref, [&](float *c, uint32_t ldc) {
-            return mispmm_bsrc_bf16(nullptr, a->numBlockRows, K, nSteps, dsp, dcl, dtl, b16, N, N, c, ldc, 0);
+        delete runWrapper<DT, MT>(shape, 4, db, &ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            return mispmm_bsrc_bf16(stream, a->numBlockRows, K, nSteps, dsp, dcl, dtl, b16, N, N, c, ldc, 0);
         });
         if (a->blockColSize == 16) {
-            delete runWrapper<DT, MT>(shape, 5, db, &ref, [&](float *c, uint32_t ldc) {
-                return mispmm_bsr_bf16(nullptr, a->numBlockRows, K, 16, 16, a->numBlocks, da->blockRowPtrs, da->blockColIdxs, blocks16, b16,
+            delete runWrapper<DT, MT>(shape, 5, db, &ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+                return mispmm_bsr_bf16(stream, a->numBlockRows, K, 16, 16, a->numBlocks, da->blockRowPtrs, da->blockColIdxs, blocks16, b16,
                                        N, N, c, ldc, 0);
             });
         }

@@ -42,9 +42,9 @@ DenseMatrix<DT, MT> *spmmCOOWrapper(int kernelNum, SparseMatrixCOO<DT, MT> *a, D
             mispmmCheckError(mispmm_device_sync());
             a->rowBoundsReady = true;
         }
-        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
+        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
             if (kernelNum == 1) a->rowBoundsReady = true;
-            return mispmm_coo_f32(nullptr, a->numRows, a->numCols, a->numNonZero, a->rowIdxs, a->colIdxs, a->data, b->data,
+            return mispmm_coo_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowIdxs, a->colIdxs, a->data, b->data,
                                   b->numCols, b->numCols, c, ldc, a->rowBoundsWorkspace, kernelNum, acc);
         });
     }

@@ -40,13 +40,13 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
         const WrapperShape shape{"CSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->numNonZero * n,
                                  a->numNonZero * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
         const int acc = accModeOf<AccT>();
-        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
+        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
             if (a->uniformRowNnz > 0 && (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5)) {
-                const int st = mispmm_csr_uniform_f32(nullptr, a->numRows, a->numCols, a->uniformRowNnz, a->colIdxs, a->data,
+                const int st = mispmm_csr_uniform_f32(stream, a->numRows, a->numCols, a->uniformRowNnz, a->colIdxs, a->data,
                                                       b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;  // a B of 2 GiB or more falls through to the general call
             }
-            return mispmm_csr_f32(nullptr, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data, b->data,
+            return mispmm_csr_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data, b->data,
                                   b->numCols, b->numCols, c, ldc, kernelNum, acc);
         });
     }

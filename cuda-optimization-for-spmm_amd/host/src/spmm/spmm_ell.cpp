@@ -44,8 +44,8 @@ DenseMatrix<DT, MT> *spmmELLWrapper(int kernelNum, SparseMatrixELL<DT, MT> *a, D
         const WrapperShape shape{"ELL", a->numRows, a->numCols, a->numNonZero, 2.0 * a->numNonZero * n,
                                  (double)a->numRows * a->rowWidth * 8.0 + a->numCols * n * 4 + a->numRows * n * 4};
         const int acc = accModeOf<AccT>();
-        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc) {
-            return mispmm_ell_f32(nullptr, a->numRows, a->numCols, a->rowWidth, a->rmColIdxs, a->rmData, b->data,
+        return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            return mispmm_ell_f32(stream, a->numRows, a->numCols, a->rowWidth, a->rmColIdxs, a->rmData, b->data,
                                   b->numCols, b->numCols, c, ldc, kernelNum, acc);
         });
     }

@@ -1,10 +1,11 @@
+#include <chrono>
 #include "engine/wrapper_common.hpp"
 
 namespace cuspmm {
 
 template <typename DT, typename MT>
 DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref,
-                                const std::function<int(DT *, uint32_t)> &launch) {
+                                const std::function<int(DT *, uint32_t, mispmm_stream_t)> &launch) {
     using clock = std::chrono::high_resolution_clock;
     auto us = [](clock::time_point a, clock::time_point z) {
         return (double)std::chrono::duration_cast<std::chrono::microseconds>(z - a).count() / 1000.0;
@@ -15,7 +16,7 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
     const auto t1 = clock::now();
     auto *c = new DenseMatrix<DT, MT>(shape.rows, cols, true, ORDERING::ROW_MAJOR);
     const auto t2 = clock::now();
-    const int status = launch(c->data, cols);
+    const int status = launch(c->data, cols, nullptr);
     if (status == MISPMM_ERR_UNSUPPORTED) {
         // the kernel declines this shape: report zeros and hand back nothing, as the reference's
         // K4 does (/root/reference/src/spmm/csr/spmm_csr_k4.cu:97-101)
@@ -38,20 +39,37 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
     steady.dtype = shape.dtype;
     const int iters = engineOptions().steadyIters;
     if (iters > 0) {
+        // steady state: `iters` back-to-back launches captured into hipGraphs (chunks of <= 1000) on a stream of the
+        // wrapper and replayed -- eager launches of a 3.5 us kernel measure the host's launch rate, not the kernel
+        mispmm_stream_t st = nullptr;
+        mispmmCheckError(mispmm_stream_create(&st));
         mispmm_event_t e0 = nullptr, e1 = nullptr;
         mispmmCheckError(mispmm_event_create(&e0));
         mispmmCheckError(mispmm_event_create(&e1));
-        for (int i = 0; i < 10; ++i) mispmmCheckError(launch(c->data, cols));  // warm-up
-        mispmmCheckError(mispmm_event_record(e0, nullptr));
-        for (int i = 0; i < iters; ++i) mispmmCheckError(launch(c->data, cols));
-        mispmmCheckError(mispmm_event_record(e1, nullptr));
+        const int chunk = iters < 1000 ? iters : 1000;
+        mispmm_graph_t graph = nullptr;
+        mispmmCheckError(mispmm_graph_begin(st));
+        for (int i = 0; i < chunk; ++i) mispmmCheckError(launch(c->data, cols, st));
+        mispmmCheckError(mispmm_graph_end(st, &graph));
+        const int replays = (iters + chunk - 1) / chunk;
+        // warm-up replays for ~20 ms (graph upload, caches, clocks at their busy level)
+        for (auto w0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - w0 < std::chrono::milliseconds(20);) {
+            mispmmCheckError(mispmm_graph_launch(graph, st));
+            mispmmCheckError(mispmm_stream_sync(st));
+        }
+        mispmmCheckError(mispmm_event_record(e0, st));
+        for (int r = 0; r < replays; ++r) mispmmCheckError(mispmm_graph_launch(graph, st));
+        mispmmCheckError(mispmm_event_record(e1, st));
         mispmmCheckError(mispmm_event_sync(e1));
         float ms = 0;
         mispmmCheckError(mispmm_event_elapsed_ms(e0, e1, &ms));
+        mispmmCheckError(mispmm_graph_destroy(graph));
         mispmmCheckError(mispmm_event_destroy(e0));
         mispmmCheckError(mispmm_event_destroy(e1));
-        const double sec = (double)ms * 1e-3 / iters;
-        steady.iters = iters;
+        mispmmCheckError(mispmm_stream_destroy(st));
+        const int timed = replays * chunk;
+        const double sec = (double)ms * 1e-3 / timed;
+        steady.iters = timed;
         steady.usPerSpmm = sec * 1e6;
         steady.gflops = shape.flops / sec / 1e9;
         steady.hbmGBps = shape.algorithmicBytes / sec / 1e9;
@@ -64,6 +82,6 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
 
 template DenseMatrix<float, uint32_t> *runWrapper<float, uint32_t>(const WrapperShape &, int, DenseMatrix<float, uint32_t> *,
                                                                  DenseMatrix<float, uint32_t> *,
-                                                                 const std::function<int(float *, uint32_t)> &);
+                                                                 const std::function<int(float *, uint32_t, mispmm_stream_t)> &);
 
 }  // namespace cuspmm

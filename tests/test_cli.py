@@ -141,14 +141,14 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
     recs = [r for r, _ in records(p.stdout)]
     assert [r["kernelType"] for r in recs if r["format"] == "CSR"] == ["0", "1", "2", "3", "4", "5", "-1"]
     assert all(r["correct"] == "1" for r in recs)
-    # perf guard, a few percent under the kept numbers (profiles/r2): the CLI times eager back-to-back launches
-    # (host-bound below ~3.5 us per kernel), so its floor sits lower than bench.py's graph-replay figure
+    # perf guard under the kept numbers (profiles/r2/cli_steady_probe.log): the CLI replays its --iters launches from
+    # one hipGraph; a 100-node graph still carries the ~7 us of one graph launch, so the floor sits under bench.py's
     best = {}
     for r in recs:
         if "rooflineFrac" in r and r["kernelType"] not in ("0", "-1"):
             best[r["format"]] = max(best.get(r["format"], 0.0), float(r["rooflineFrac"]))
-    assert best["CSR"] >= 0.40, f"CSR K=128 steady-state HBM roofline fraction regressed: {best}"
-    assert best["ELL"] >= 0.40, f"ELL K=128 steady-state HBM roofline fraction regressed: {best}"
+    assert best["CSR"] >= 0.48, f"CSR K=128 steady-state HBM roofline fraction regressed: {best}"
+    assert best["ELL"] >= 0.48, f"ELL K=128 steady-state HBM roofline fraction regressed: {best}"
 
 
 @pytest.mark.gpu
