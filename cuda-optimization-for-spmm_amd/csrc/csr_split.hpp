@@ -1,0 +1,284 @@
+// CSR x dense for matrices with LONG or very uneven rows (kernel 6): a row's entries are dealt over the 8 lane groups of
+// a wave that each keep a partial sum, and the partial sums are added in a fixed order at the end.
+//
+// Why: a row's sum is sequential by the reference's contract (spmm_csr.cpp:20-25: `acc += (float)(a * b)` in entry
+// order into a double), so a kernel that keeps ONE running sum per output element needs (row length / reads in flight)
+// memory round trips for its longest row -- GL7d25's 422-entry row alone is ~9 us on an otherwise idle GPU (DESIGN.md
+// §5).  Splitting the row is a re-association of the sum.  In FAST mode that is allowed outright.  In REFERENCE mode it
+// is allowed WHEN IT CANNOT CHANGE THE RESULT, which is decided per lane (4 output elements) from two numbers tracked
+// alongside the sums:
+//   every product p is an fp32 value, i.e. an integer multiple of ulp32(p) > 2^-24 |p|.  With u = 2^-24 min|p| over the
+//   non-zero products of the row, every partial sum in ANY order is a multiple of u no larger than sum|p| <= L max|p|.
+//   If L max|p| <= 2^29 min|p| every such partial sum is below 2^53 u and therefore exactly representable in fp64: no
+//   addition rounds, in any order, so the split sum and the reference's sequential sum are the same double, and the
+//   final rounding to fp32 sees the same value.  (2^28 is used: one bit of slack for evaluating the test in fp32.)
+// Zero products are exact in any sum and are left out of min|p|.  A wave with an element that fails the test (a product
+// 2^19.. times smaller than the largest of a 400-entry row, an Inf / NaN, a huge value) sums its 32 columns again IN
+// ENTRY ORDER: the same pass with the same 64 entries in flight, but each pair of steps lists its 16 x 32 products in
+// LDS and lanes 0..31 add their column's 16 terms in order -- bit-exact always, fast when the data allows.  (Measured on
+// the way: a thread that walks the row on its own pays two dependent memory round trips per entry -- ONE such element
+// of a 170-entry row took GL7d25 from 11.7 to 35 us; a wave re-reading the row one entry per step, 26 us.)
+//
+// Shape: one WAVE per row x 32 output columns: 8 lanes x 16 bytes read one 128-byte segment of a B row, a wave
+// multiplies 8 entries per step, and the 32-column parts of a row go to DIFFERENT XCDs (P row parts x Q column parts
+// over the 8 XCDs, Q = up to 8).  Each XCD's L2 then only ever sees its own 128-byte columns of B.  On a matrix whose
+// rows scatter over all of B (GL7d25: 29 entries per row over 21 074 columns) a workgroup-per-row variant reading
+// whole 512-byte B rows made every XCD fetch 4-8 MB against its 4 MB of L2, time proportional to N (N = 128 / 256:
+// 10.9 / 21.3 us FAST); this shape fetches 21 074 x 128 bytes per XCD, which fits (6.9 / 9.8 us).
+// Everything is wave-private (strip, partial sums, ordered re-sum): no workgroup barrier, a wave leaves when its row is done.
+#pragma once
+#include "spmm_common.hpp"
+
+namespace mispmm {
+
+// max|p| and min non-zero |p| of the products a lane has added (REFERENCE mode only).  The minimum is kept as
+// 2 * bits(|p|) - 1 (unsigned): monotone in |p|, and a zero product wraps to 0xFFFFFFFF so it never wins.
+struct ExactTrack {
+    float hi = 0.f;
+    uint32_t lo = 0xFFFFFFFFu;
+    __device__ __forceinline__ void add2(float p0, float p1) {
+        hi = __builtin_fmaxf(hi, __builtin_fmaxf(__builtin_fabsf(p0), __builtin_fabsf(p1)));
+        const uint32_t t0 = (__float_as_uint(p0) << 1) + 0xFFFFFFFFu, t1 = (__float_as_uint(p1) << 1) + 0xFFFFFFFFu;
+        lo = min(lo, min(t0, t1));
+    }
+};
+
+// true when the fp64 sum of `len` fp32 products with the given extremes is exact in every order (see the header)
+__device__ __forceinline__ bool reassociation_is_exact(uint32_t len, float hi, uint32_t lo) {
+    if (lo == 0xFFFFFFFFu) return hi == 0.f;  // only zero products (or none)
+    const float smallest = __uint_as_float((lo + 1u) >> 1);
+    return len < (1u << 24) && hi < 0x1p100f && static_cast<float>(len) * hi <= 0x1p28f * smallest;
+}
+
+#ifdef MISPMM_TUNING
+// measurement build only: [0] waves that summed their row again in entry order since the last reset
+__device__ unsigned long long mispmm_split_stats[2];
+#endif
+
+struct SplitTiling {
+    uint32_t p, q;           // row parts x column parts over the XCDs, p * q == 8
+    uint32_t rows_per_part;  // ceil(M / p)
+    uint32_t grid_x, grid_y;
+};
+
+inline SplitTiling split_tiling(uint32_t M, uint32_t N, uint32_t waves) {
+    const uint32_t colparts = ceil_div(N, 32u);
+    uint32_t q = 1;
+    while (q < 8u && q < colparts) q <<= 1;
+    SplitTiling t;
+    t.q = q;
+    t.p = 8u / q;
+    t.rows_per_part = ceil_div(M, t.p);
+    t.grid_x = 8u * ceil_div(t.rows_per_part, waves);  // a multiple of 8: workgroup id % 8 == blockIdx.x % 8 in every grid row
+    t.grid_y = ceil_div(colparts, q);
+    return t;
+}
+
+template <class Acc, int WAVES, int NB>
+__global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                                        const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                                        const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                                        float *__restrict__ C, uint32_t ldc, uint32_t tile_q,
+                                                        uint32_t rows_per_part) {
+    using u2 = uint32_t __attribute__((ext_vector_type(2)));
+    using T = typename Acc::T;
+    constexpr bool kRef = std::is_same_v<Acc, AccRefWide>;
+    constexpr int G = 8;          // lanes per entry: 8 x 4 columns = one 128-byte segment of a B row
+    constexpr int OWN = 8;        // entries per step = lane groups = partial sums per output element
+    constexpr int COLS = 32;
+    constexpr int RING = NB * 4;  // B-segment reads in flight per lane, refilled in blocks of 4 steps
+    constexpr int PHASE = 512;    // entries staged in LDS at a time
+    static_assert(PHASE % (RING * OWN) == 0, "staging is padded to whole rings");
+    // per wave: the staged entries | the partial sums (8 groups x 32 columns), reused by the ordered re-sum as the list
+    // of the products of two steps (16 entries x 32 columns, fp32)
+    constexpr int kStripBytes = PHASE * 8;
+    constexpr int kPartBytes = OWN * COLS * static_cast<int>(sizeof(T)) > 16 * COLS * 4 ? OWN * COLS * static_cast<int>(sizeof(T)) : 16 * COLS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES][kStripBytes + kPartBytes];
+    __shared__ float track_hi_all[kRef ? WAVES * OWN * G : 1];
+    __shared__ uint32_t track_lo_all[kRef ? WAVES * OWN * G : 1];
+
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    // workgroups are dealt round-robin over the XCDs: blockIdx.x & 7 is the XCD, which owns one (row part, column part).
+    // Placement only: any dispatch order gives the same result.
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t part_row = xcd / tile_q, part_col = xcd % tile_q;
+    const uint32_t local = (blockIdx.x >> 3) * WAVES + wave;
+    const uint32_t row = part_row * rows_per_part + local;
+    const uint32_t slab = (blockIdx.y * tile_q + part_col) * COLS;
+    if (local >= rows_per_part || row >= M || slab >= N) return;  // wave-uniform; there is no workgroup barrier below
+    const uint32_t li = lane % G;
+    const uint32_t group = lane / G;
+    const uint32_t col0 = slab + li * 4u;
+    const uint32_t lane_off = col0 < N ? col0 * 4u : kDropLoad;
+    const rsrc_t rsrc = make_rsrc(B, b_bytes);
+    const uint32_t ldb4 = ldb * 4u;
+    const uint32_t start = __builtin_amdgcn_readfirstlane(rowPtrs[row]);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(rowPtrs[row + 1]);
+    u2 *const strip = reinterpret_cast<u2 *>(smem[wave]);
+    T *const part = reinterpret_cast<T *>(smem[wave] + kStripBytes);
+    float *const listed = reinterpret_cast<float *>(smem[wave] + kStripBytes);
+    float *const track_hi = track_hi_all + (kRef ? wave * OWN * G : 0);
+    uint32_t *const track_lo = track_lo_all + (kRef ? wave * OWN * G : 0);
+    // a wave's LDS is its own and a wave's LDS operations complete in order; this keeps the compiler from moving reads
+    // ahead of the writes they depend on
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    // the same between LDS operations only, for use while B reads are in flight: a fence would wait for those too
+    // (measured: the ordered re-sum of a 392-entry row 7.6 us with fences, every list waiting out the whole ring)
+    auto lds_order = [] {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    T acc[4] = {0, 0, 0, 0};
+    ExactTrack track;
+    double ordered = 0;  // ordered re-sum: the running sum of column `lane` (lanes 0..31)
+    // One pass over the row, entry i read by lane group i % 8 in step i / 8.  kOrdered == false: every group adds its
+    // products to its own partial sums.  kOrdered == true: the products go through LDS and are added in entry order.
+    auto sweep = [&](auto ordered_tag) {
+        constexpr bool kOrdered = decltype(ordered_tag)::value;
+        for (uint32_t base = start; base < end; base += PHASE) {
+            const uint32_t n = min(static_cast<uint32_t>(PHASE), end - base);
+            const uint32_t steps = (n + OWN - 1u) / OWN;
+            const uint32_t nring = (steps + RING - 1u) / RING;
+            wave_sync();  // the previous phase / the partial sums have been read
+            // (byte offset of the B row, coefficient); the padding up to whole rings is (dropped load, 0): exact no-ops.
+            // A row of one phase is still staged when the ordered pass comes round.
+            if (!kOrdered || end - start > static_cast<uint32_t>(PHASE)) {
+                for (uint32_t i = lane; i < nring * (RING * OWN); i += 64u) {
+                    u2 pair{kDropLoad, 0u};
+                    if (i < n) {
+                        pair[0] = colIdxs[base + i] * ldb4;
+                        pair[1] = __float_as_uint(vals[base + i]);
+                    }
+                    strip[i] = pair;
+                }
+                wave_sync();
+            }
+
+            f32x4 bv[RING];
+            float av[RING];
+            auto issue_block = [&](uint32_t blk, auto ring_tag) {
+                constexpr int R = decltype(ring_tag)::value;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const u2 pair = strip[(blk * 4u + t) * OWN + group];  // one address per lane group: LDS broadcasts
+                    av[R * 4 + t] = __uint_as_float(pair[1]);
+                    bv[R * 4 + t] = buffer_load_vec<4>(rsrc, pair[0] + lane_off, 0);
+                }
+            };
+            auto consume_block = [&](auto ring_tag) {
+                constexpr int R = decltype(ring_tag)::value;
+                if constexpr (kOrdered) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        lds_order();  // the previous list has been added up
+#pragma unroll
+                        for (int t = 2 * half; t < 2 * half + 2; ++t) {
+                            const f32x4 b = bv[R * 4 + t];
+                            const float a = av[R * 4 + t];
+                            // entry (step, group) -> list row (step % 2) * 8 + group: entry order
+                            *reinterpret_cast<f32x4 *>(listed + ((t & 1) * OWN + group) * COLS + li * 4u) =
+                                f32x4{a * b[0], a * b[1], a * b[2], a * b[3]};
+                        }
+                        lds_order();
+                        if (lane < COLS) {
+                            float term[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) term[k] = listed[k * COLS + lane];
+                            // past the row's end the products are +0.0 (dropped load x 0), and sum + 0.0 == sum: the
+                            // running sum starts at +0.0 and so is never -0.0
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) ordered += static_cast<double>(term[k]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 b = bv[R * 4 + t];
+                        if constexpr (kRef) {
+                            using f2 = float __attribute__((ext_vector_type(2)));
+                            const f2 a2{av[R * 4 + t], av[R * 4 + t]};
+                            const f2 p01 = a2 * f2{b[0], b[1]}, p23 = a2 * f2{b[2], b[3]};
+                            acc[0] += static_cast<double>(p01[0]);
+                            acc[1] += static_cast<double>(p01[1]);
+                            acc[2] += static_cast<double>(p23[0]);
+                            acc[3] += static_cast<double>(p23[1]);
+                            track.add2(p01[0], p01[1]);
+                            track.add2(p23[0], p23[1]);
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) Acc::mac(acc[v], av[R * 4 + t], b[v]);
+                        }
+                    }
+                }
+            };
+            auto pin = [&] {  // a refill reuses the registers just consumed: keep it behind the sums (see row_gather.hpp)
+                if constexpr (kOrdered) asm volatile("" : "+v"(ordered) : : "memory");
+                else asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+            };
+            static_for<0, NB>([&](auto r) { issue_block(decltype(r)::value, r); });
+            uint32_t b0 = 0;
+            for (; b0 + NB < nring * NB; b0 += NB) {  // steady state: RING reads in flight, each block refilled as consumed
+                static_for<0, NB>([&](auto r) {
+                    consume_block(r);
+                    pin();
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_block(b0 + NB + decltype(r)::value, r);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            // the last ring: blocks past the row's end hold only padding, skip their arithmetic
+            static_for<0, NB>([&](auto r) {
+                if ((b0 + decltype(r)::value) * 4u < steps) consume_block(r);
+            });
+        }
+    };
+    sweep(std::false_type{});
+
+    // partial sums -> LDS, then lanes 0..31 add their column's 8 partial sums in group order
+    wave_sync();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[group * COLS + li * 4u + v] = acc[v];
+    if constexpr (kRef) {
+        track_hi[group * G + li] = track.hi;
+        track_lo[group * G + li] = track.lo;
+    }
+    wave_sync();
+    const bool mine = lane < COLS && slab + lane < N;
+    T total = 0;
+    bool redo = false;
+    if (mine) {
+        total = part[lane];
+#pragma unroll
+        for (int o = 1; o < OWN; ++o) total += part[o * COLS + lane];
+        if constexpr (kRef) {
+            float hi = track_hi[lane / 4u];
+            uint32_t lo = track_lo[lane / 4u];
+#pragma unroll
+            for (int o = 1; o < OWN; ++o) {
+                hi = __builtin_fmaxf(hi, track_hi[o * G + lane / 4u]);
+                lo = min(lo, track_lo[o * G + lane / 4u]);
+            }
+            // NaN products do not reach `hi` (fmax drops them) but do reach the sum
+            redo = !reassociation_is_exact(end - start, hi, lo) || total != total;
+        }
+    }
+    if constexpr (kRef) {
+        if (__ballot(redo) != 0) {  // wave-uniform
+#ifdef MISPMM_TUNING
+            if (lane == 0) atomicAdd(&mispmm_split_stats[0], 1ull);
+#endif
+            sweep(std::true_type{});
+            total = ordered;
+        }
+    }
+    if (mine) C[static_cast<size_t>(row) * ldc + slab + lane] = Acc::finish(total);
+}
+
+}  // namespace mispmm

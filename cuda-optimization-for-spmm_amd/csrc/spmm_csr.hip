@@ -18,6 +18,7 @@
 // Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
 #include "row_gather.hpp"
+#include "csr_split.hpp"
 
 namespace mispmm {
 
@@ -523,6 +524,26 @@ static void launch_wave_deep(const CsrArgs &a) {
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }
 
+template <class Acc, int WAVES, int NB>
+static void launch_split_as(const CsrArgs &a) {
+    const SplitTiling t = split_tiling(a.M, a.N, WAVES);
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    note_kernel("csr_split<W%d,R%d,%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), t.p, t.q);
+    hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream, a.M, a.rowPtrs,
+                       a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q, t.rows_per_part);
+}
+
+// one wave per row x 32 columns, the row's entries dealt over its 8 lane groups (csr_split.hpp).  GL7d25, us REFERENCE /
+// FAST at N = 128 with 4 / 8 / 16 reads in flight per lane: 10.4 / 6.8, 9.9 / 6.9, 12.2 / 9.5; 1, 2 or 4 waves per
+// workgroup make no difference.
+template <class Acc>
+static void launch_split(const CsrArgs &a) {
+    static const int ring = knob_int("MISPMM_SPLIT_RING", 8);
+    if (ring == 4) launch_split_as<Acc, 4, 1>(a);
+    else if (ring == 16) launch_split_as<Acc, 4, 4>(a);
+    else launch_split_as<Acc, 4, 2>(a);
+}
+
 template <class Acc>
 static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     // buffer offsets are 32-bit and bit 31 marks a dropped load: a B of 2 GiB or more takes the
@@ -532,8 +553,24 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     // forces the choice (measurement aid; results do not depend on it).
     static const int long_env = knob_int("MISPMM_LONGROWS", -1);
     const bool long_rows = long_env >= 0 ? long_env != 0 : (a.M != 0 && a.nnz / a.M >= 24);
-    // ... up to 256 output columns: from 384 on the lane-group kernel with 16 reads in flight is faster again (GL7d25,
-    // REFERENCE us, deep wave / lane group: N = 128 17.2 / 22.9, 256 26.2 / 29.1, 384 39.4 / 37.4, 512 44.5 / 30.2)
+    // kernel 6, and kernel 5 on long rows: the row split over the lane groups of a wave (csr_split.hpp); needs 16-byte
+    // B rows.  GL7d25 (mean 29, longest 422 entries), us at N = 64 / 128 / 256 / 512:
+    //   REFERENCE, no element needs the ordered re-sum   7.9 /  9.8 / 13.9 / 28.1
+    //   REFERENCE, every wave re-sums (B spread over 2^60) 14.2 / 17.3 / 23.8 / 43.4
+    //   REFERENCE before (deep wave / lane group)       13.9 / 17.4 / 27.5 / 30.8
+    //   FAST 5.3 / 6.8 / 10.0 / 22.5 (before: 15.2 at N = 128)
+    // so REFERENCE mode keeps the lane-group kernel from N = 384 on, where the bad case costs more than the good one
+    // gains.  MISPMM_SPLIT=0 keeps kernel 5 off the split kernel altogether (measurement aid).
+    static const int split_env = knob_int("MISPMM_SPLIT", 1);
+    const bool split_pays = std::is_same_v<Acc, AccFast> || a.N < 384;
+    if (!wide && vec == 4 && (kernel == 6 || (kernel == 5 && long_rows && split_env != 0 && split_pays))) {
+        launch_split<Acc>(a);
+        return;
+    }
+    if (kernel == 6) kernel = 5;  // shapes the split kernel does not take
+    // long rows without 16-byte B rows: the deep wave-per-row kernel up to 256 output columns; from 384 on the lane-group
+    // kernel with 16 reads in flight is faster again (GL7d25, REFERENCE us, deep wave / lane group: N = 128 17.2 / 22.9,
+    // 256 26.2 / 29.1, 384 39.4 / 37.4, 512 44.5 / 30.2)
     if (kernel == 5 && !wide && long_rows && (long_env == 1 || a.N < 384)) {
         int v = vec;
         while (v > 1 && 64u * (v / 2) >= a.N) v /= 2;
@@ -577,6 +614,18 @@ using namespace mispmm;
 // diagnostic build only: where the row-gather waves of THIS translation unit leave their stamps (8 x uint64 per wave)
 extern "C" int mispmm_debug_set_stamps(void *device_buffer) {
     MISPMM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mispmm_stamp_buf), &device_buffer, sizeof(device_buffer)));
+    return MISPMM_OK;
+}
+#endif
+
+#ifdef MISPMM_TUNING
+// measurement build only (libmispmm_tune.so): how often csr_split had to leave the split sum since the last call --
+// out[0] waves that summed their row again in entry order (out[1] unused).  Synchronises the device.
+extern "C" int mispmm_debug_split_stats(unsigned long long out[2]) {
+    const unsigned long long zero[2] = {0, 0};
+    MISPMM_HIP_TRY(hipDeviceSynchronize());
+    MISPMM_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(mispmm_split_stats), sizeof(zero)));
+    MISPMM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mispmm_split_stats), zero, sizeof(zero)));
     return MISPMM_OK;
 }
 #endif

@@ -126,12 +126,16 @@ int mispmm_graph_destroy(mispmm_graph_t graph);
  *         2 row-block workgroup, (col,val) staged through LDS;
  *         3 wave-per-row, (col,val) on the scalar path, B rows by SGPR base;
  *         4 as 3 with two rows in flight per wave;
- *         5 as 1 with a 2-D (row part x column part) XCD tiling and write-through C stores.
+ *         5 as 1 with a 2-D (row part x column part) XCD tiling and write-through C stores (auto: rows of
+ *           24 entries or more on average take kernel 6);
+ *         6 one workgroup per row, the row's entries split over its lane groups (long or very uneven rows).
+ *           REFERENCE mode stays bit-exact: an output element is summed in split order only where that
+ *           provably cannot round differently, else sequentially (csrc/csr_split.hpp).
  * Any kernel id handles any M, K, nnz, N, ragged and empty rows. */
 int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
                    const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
                    uint32_t ldc, int kernel, int acc_mode);
-#define MISPMM_CSR_NUM_KERNELS 5
+#define MISPMM_CSR_NUM_KERNELS 6
 
 /* Structure hint: a CSR whose rows ALL hold exactly rowNnz entries (rowPtrs[r] == r * rowNnz, e.g. the
  * headline matrix n4c6-b13 with 14, or any ELL-shaped CSR).  Same arithmetic and results as

@@ -60,7 +60,7 @@ CSR_CASES = [("Hamrle1", [1, 3, 32]), ("n3c5-b6", [8, 21]), ("qh1484", [64, 130]
              ("GL7d25", [64, 100]), ("ACTIVSg10K", [128]), ("n4c6-b13", [128, 256, 512, 515])]
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("name,ns", CSR_CASES)
 def test_csr_matches_oracle(oracle, name, ns, kernel):
     csr = datasets.load_csr(name)
@@ -108,8 +108,9 @@ def test_uniform_rows_every_slot_count(oracle, width):
 
 @pytest.mark.parametrize("n", [1, 64, 130, 256, 512])
 def test_csr_long_row_kernel(oracle, n):
-    """Mean row length >= 24 sends kernel 0/5 to the deep wave-per-row kernel (csr_wave_deep): rows of 0, 1, 7, 8, 9
-    entries, rows at and around its 512-entry LDS phase, a 1500-entry row; every vector width; bit-exact."""
+    """Mean row length >= 24 sends kernel 0/5 to the split kernel (16-byte B rows, N < 384), else to the deep
+    wave-per-row kernel (csr_wave_deep; the lane-group kernel from N = 384 on): rows of 0, 1, 7, 8, 9 entries, rows at and
+    around the 512-entry LDS phase, a 1500-entry row; every vector width; bit-exact."""
     lens = [0, 1, 7, 8, 9, 511, 512, 513, 1500, 0, 64, 33, 40, 25, 31, 200]
     csr = random_csr(len(lens), 2000, lens, seed=11)
     assert csr.nnz // csr.num_rows >= 24
@@ -130,7 +131,7 @@ def test_csr_long_row_kernel(oracle, n):
     assert torch.all(cw[:, n:] == -7.0)
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 5, 6])
 def test_csr_ragged_rows_and_edges(oracle, kernel):
     """Empty rows, rows of 1, 17, 64, 65, 200 and 2500 entries (k2 re-stages LDS past 1024
     pairs, k3/k4 loop 64-pair chunks), M not a multiple of any tile."""
@@ -144,7 +145,7 @@ def test_csr_ragged_rows_and_edges(oracle, kernel):
         assert np.array_equal(c, ref), f"N={n}"
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5, 6])
 def test_csr_strided_and_unaligned_operands(oracle, kernel):
     csr = datasets.load_csr("qh1484")
     a = ops.DeviceCSR.from_host(csr)
@@ -196,6 +197,105 @@ def test_csr_empty_and_overwrite():
     assert ops.spmm_csr(ops.DeviceCSR.from_host(none), torch.ones(9, 4, device="cuda")).shape == (0, 4)
 
 
+@pytest.mark.parametrize("n", [4, 60, 64, 128, 200, 256, 512])
+def test_csr_split_row_kernel(oracle, n):
+    """Kernel 6 (one wave per row x 32 columns, entries dealt over its 8 lane groups; csr_split.hpp) and kernel 0 on long
+    rows: REFERENCE mode is bit-exact with the sequential engine whether a wave keeps the split sum (uniform B), or sums
+    again in entry order because the re-association test fails -- products spread over 2^60, a NaN, an Inf, values near
+    the fp32 limits -- and for rows of 0, 1, 7..9 entries, around the 512-entry LDS phase, 2500 entries."""
+    lens = [0, 1, 7, 8, 9, 31, 32, 33, 511, 512, 513, 1025, 2500, 0, 64, 40, 25, 200, 422]
+    csr = random_csr(len(lens), 3000, lens, seed=17)
+    a = ops.DeviceCSR.from_host(csr)
+    b = synth.dense_b(csr.num_cols, n)
+    rng = np.random.default_rng(5)
+    wide = b * np.exp2(rng.integers(-30, 31, size=b.shape)).astype(np.float32)   # every long row fails the test
+    sparse_b = np.where(rng.random(b.shape) < 0.5, np.float32(0), b)              # zero products are left out of it
+    few = b.copy()                                                                # a few elements per row fail it
+    few[rng.integers(0, b.shape[0], 40), rng.integers(0, n, 40)] *= np.float32(2.0 ** -40)
+    special = b.copy()
+    special[csr.col_idxs[40], 0] = np.inf
+    special[csr.col_idxs[2000], n - 1] = np.nan
+    special[csr.col_idxs[3000], n // 2] = np.float32(3e38)
+    special[csr.col_idxs[3001], n // 2] = np.float32(-3e38)
+    special[csr.col_idxs[100], 1] = np.float32(1e-44)                               # a denormal
+    for name, bb in (("uniform", b), ("wide", wide), ("zeros", sparse_b), ("few", few), ("special", special)):
+        with np.errstate(all="ignore"):
+            ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, bb)
+        for kernel in (6, 0):
+            c = ops.spmm_csr(a, dev(bb), kernel=kernel, acc="reference").cpu().numpy()
+            assert np.array_equal(c, ref, equal_nan=True), (name, kernel, n)
+    assert ("csr_split" in capi.last_kernel()) == (n < 384)   # REFERENCE mode, kernel 0: the lane-group kernel from 384 on
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    fast = ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy()
+    assert_fast_close(fast, ref, abs_scale(csr, b))
+    assert np.array_equal(fast, ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy())   # fixed-order reduction
+    # a strided C / B (ldb, ldc > N)
+    ld = n + 12
+    bw = torch.zeros((csr.num_cols, ld), dtype=torch.float32, device="cuda")
+    bw[:, :n] = dev(b)
+    cw = torch.full((csr.num_rows, ld), -7.0, dtype=torch.float32, device="cuda")
+    ops.spmm_csr(a, bw[:, :n], out=cw[:, :n], kernel=6)
+    assert np.array_equal(cw[:, :n].cpu().numpy(), ref)
+    assert torch.all(cw[:, n:] == -7.0)
+
+
+def test_csr_split_row_kernel_on_real_matrices(oracle):
+    """GL7d25 (mean 29, longest 422 entries; integer coefficients) and tols4000 (mean 2, longest 90) through kernel 6."""
+    for name in ("GL7d25", "tols4000", "n4c6-b13"):
+        csr = datasets.load_csr(name)
+        a = ops.DeviceCSR.from_host(csr)
+        for n in (128, 256):
+            b = synth.dense_b(csr.num_cols, n)
+            ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+            assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6, use_hint=False).cpu().numpy(), ref), (name, n)
+            assert "csr_split" in capi.last_kernel()
+
+
+def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tmp_path):
+    """The measurement build counts the waves of kernel 6 that summed their row again in entry order: none on grid
+    data, a handful on uniform data (products 2^19.. apart in rows of hundreds of entries), every wave with entries
+    when B spreads over 2^60 -- and the results are the reference's bits in all three cases."""
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-optimization-for-spmm_amd")
+    tune = os.path.join(pkg, "libmispmm_tune.so")
+    assert os.path.exists(tune), "run `make -C cuda-optimization-for-spmm_amd tune`"
+    code = (
+        "import ctypes, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {pkg!r})\n"
+        "from mispmm import capi, datasets, ops, synth\n"
+        "l = capi.lib()\n"
+        "def resummed():\n"
+        "    out = (ctypes.c_ulonglong * 2)()\n"
+        "    capi.check(l.mispmm_debug_split_stats(out))\n"
+        "    return int(out[0])\n"
+        "csr = datasets.load_csr('GL7d25')\n"
+        "a = ops.DeviceCSR.from_host(csr)\n"
+        "uni = synth.dense_b(csr.num_cols, 128)\n"
+        "wide = uni * np.exp2(np.random.default_rng(1).integers(-30, 31, size=uni.shape)).astype(np.float32)\n"
+        "res = {}\n"
+        "for tag, b in (('grid', synth.dense_b(csr.num_cols, 128, mode='exact')), ('uniform', uni), ('wide', wide)):\n"
+        "    resummed()\n"
+        "    res[tag] = ops.spmm_csr(a, torch.from_numpy(b).cuda(), kernel=6).cpu().numpy()\n"
+        "    res[tag + '_resummed'] = np.array(resummed())\n"
+        "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **res)\n")
+    path = str(tmp_path / "split.npz")
+    p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_LIB=tune), capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = np.load(path)
+    assert "csr_split" in str(res["tag"])
+    csr = datasets.load_csr("GL7d25")
+    uni = synth.dense_b(csr.num_cols, 128)
+    wide = uni * np.exp2(np.random.default_rng(1).integers(-30, 31, size=uni.shape)).astype(np.float32)
+    for tag, b in (("grid", synth.dense_b(csr.num_cols, 128, mode="exact")), ("uniform", uni), ("wide", wide)):
+        assert np.array_equal(res[tag], oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)), tag
+    waves = int((np.diff(csr.row_ptrs.astype(np.int64)) > 0).sum()) * 4
+    assert int(res["grid_resummed"]) == 0
+    assert 0 < int(res["uniform_resummed"]) <= 40
+    assert int(res["wide_resummed"]) >= 0.9 * waves
+
+
 def test_csr_nonfinite_values_follow_the_reference(oracle):
     csr = random_csr(4, 40, [3, 14, 16, 20], seed=3)
     b = synth.dense_b(40, 64)
@@ -203,7 +303,7 @@ def test_csr_nonfinite_values_follow_the_reference(oracle):
     b[csr.col_idxs[20], 7] = np.nan
     ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
     a = ops.DeviceCSR.from_host(csr)
-    for k in (1, 2, 3, 4, 5):
+    for k in (1, 2, 3, 4, 5, 6):
         c = ops.spmm_csr(a, dev(b), kernel=k).cpu().numpy()
         assert np.array_equal(c, ref, equal_nan=True)
 
@@ -217,7 +317,7 @@ def test_exact_grid_inputs_make_every_kernel_and_format_agree_bitwise(oracle):
     ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
     bd = dev(b)
     a = ops.DeviceCSR.from_host(csr)
-    for k in (1, 2, 3, 4, 5):
+    for k in (1, 2, 3, 4, 5, 6):
         for acc in ("reference", "fast"):
             assert np.array_equal(ops.spmm_csr(a, bd, kernel=k, acc=acc).cpu().numpy(), ref)
     ell = ops.DeviceELL.from_host(formats.csr_to_ell_colmajor(csr))

@@ -60,7 +60,7 @@ def test_sparsity_sweep_harness(tmp_path):
                        timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("density")]
-    assert len(lines) == 2 * (7 + 4)                  # CSR: kernels 0-5 and rocSPARSE; COO: 0, 1, 2 and rocSPARSE
+    assert len(lines) == 2 * (8 + 4)                  # CSR: kernels 0-6 and rocSPARSE; COO: 0, 1, 2 and rocSPARSE
     ours = [l for l in lines if " kernel -1 " not in l]
     assert all(" correct 1 " in l for l in ours), [l for l in ours if " correct 1 " not in l]
     assert os.path.getsize(out / "sparsity.json") > 0
