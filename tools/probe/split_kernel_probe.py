@@ -23,6 +23,18 @@ def main():
     widths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128, 256, 512]
     for name in names:
         csr = datasets.load_csr(name)
+        cut = int(os.environ.get("PROBE_CUT_ROWS", "0"))
+        if cut:  # timing experiment: every row longer than `cut` becomes several rows of at most `cut` entries
+            from mispmm import formats
+            ptr = [0]
+            for r in range(csr.num_rows):
+                s0, e0 = int(csr.row_ptrs[r]), int(csr.row_ptrs[r + 1])
+                while e0 - s0 > cut:
+                    s0 += cut
+                    ptr.append(s0)
+                ptr.append(e0)
+            csr = formats.CSR(len(ptr) - 1, csr.num_cols, np.asarray(ptr, np.uint32), csr.col_idxs, csr.data)
+            print(json.dumps({"cut_rows": cut, "rows": csr.num_rows}), flush=True)
         a = ops.DeviceCSR.from_host(csr)
         for n in widths:
             mode = os.environ.get("PROBE_B_MODE", "uniform")
