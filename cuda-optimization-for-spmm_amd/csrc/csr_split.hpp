@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
                                                         const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
                                                         const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
                                                         float *__restrict__ C, uint32_t ldc, uint32_t tile_q,
-                                                        uint32_t rows_per_part) {
+                                                        uint32_t rows_per_part, const uint32_t *__restrict__ spans) {
     using u2 = uint32_t __attribute__((ext_vector_type(2)));
     using T = typename Acc::T;
     constexpr bool kRef = std::is_same_v<Acc, AccRefWide>;
@@ -104,17 +104,32 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t part_row = xcd / tile_q, part_col = xcd % tile_q;
     const uint32_t local = (blockIdx.x >> 3) * WAVES + wave;
-    const uint32_t row = part_row * rows_per_part + local;
+    // Without spans: row part k is the k-th contiguous range of rows, walked in row order.  With spans -- the rows as
+    // (row, start, end, 0) sorted by decreasing length, built once per matrix on the host -- row part k takes the
+    // positions k, k + P, .. of that order: the longest rows start first and every XCD gets an equal share of them.
+    // (GL7d25 is sorted the other way round, every row longer than 128 entries among its last 93: in row order they all
+    // start last and decide when the kernel ends.)
+    const uint32_t position = spans ? local * (8u / tile_q) + part_row : part_row * rows_per_part + local;
     const uint32_t slab = (blockIdx.y * tile_q + part_col) * COLS;
-    if (local >= rows_per_part || row >= M || slab >= N) return;  // wave-uniform; there is no workgroup barrier below
+    if (local >= rows_per_part || position >= M || slab >= N) return;  // wave-uniform; there is no workgroup barrier below
     const uint32_t li = lane % G;
     const uint32_t group = lane / G;
     const uint32_t col0 = slab + li * 4u;
     const uint32_t lane_off = col0 < N ? col0 * 4u : kDropLoad;
     const rsrc_t rsrc = make_rsrc(B, b_bytes);
     const uint32_t ldb4 = ldb * 4u;
-    const uint32_t start = __builtin_amdgcn_readfirstlane(rowPtrs[row]);
-    const uint32_t end = __builtin_amdgcn_readfirstlane(rowPtrs[row + 1]);
+    uint32_t row, start, end;
+    if (spans) {  // kernel-uniform
+        using u4 = uint32_t __attribute__((ext_vector_type(4)));
+        const u4 span = *reinterpret_cast<const u4 *>(spans + static_cast<size_t>(position) * 4u);
+        row = __builtin_amdgcn_readfirstlane(span[0]);
+        start = __builtin_amdgcn_readfirstlane(span[1]);
+        end = __builtin_amdgcn_readfirstlane(span[2]);
+    } else {
+        row = position;
+        start = __builtin_amdgcn_readfirstlane(rowPtrs[row]);
+        end = __builtin_amdgcn_readfirstlane(rowPtrs[row + 1]);
+    }
     u2 *const strip = reinterpret_cast<u2 *>(smem[wave]);
     T *const part = reinterpret_cast<T *>(smem[wave] + kStripBytes);
     float *const listed = reinterpret_cast<float *>(smem[wave] + kStripBytes);

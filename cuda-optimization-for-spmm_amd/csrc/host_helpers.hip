@@ -66,6 +66,30 @@ extern "C" int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs
     return MISPMM_OK;
 }
 
+// The rows of a CSR as (row, start, end, 0), longest first (ties in row order: a counting sort by length, stable).
+extern "C" int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t *spans_out_host) {
+    if (M == 0) return MISPMM_OK;
+    if (!rowPtrs_host || !spans_out_host) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: null argument");
+    uint32_t longest = 0;
+    for (uint32_t r = 0; r < M; ++r) {
+        if (rowPtrs_host[r + 1] < rowPtrs_host[r]) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: row pointers decrease at row %u", r);
+        longest = std::max(longest, rowPtrs_host[r + 1] - rowPtrs_host[r]);
+    }
+    // first position of every length in the descending order
+    std::vector<uint32_t> first(static_cast<size_t>(longest) + 2, 0);
+    for (uint32_t r = 0; r < M; ++r) ++first[longest - (rowPtrs_host[r + 1] - rowPtrs_host[r]) + 1];
+    for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
+    for (uint32_t r = 0; r < M; ++r) {
+        const uint32_t len = rowPtrs_host[r + 1] - rowPtrs_host[r];
+        uint32_t *span = spans_out_host + static_cast<size_t>(first[longest - len]++) * 4u;
+        span[0] = r;
+        span[1] = rowPtrs_host[r];
+        span[2] = rowPtrs_host[r + 1];
+        span[3] = 0;
+    }
+    return MISPMM_OK;
+}
+
 extern "C" int mispmm_coo_sort_by_row_host(uint32_t M, uint32_t nnz, const uint32_t *rowIdxs_host,
                                            const uint32_t *colIdxs_host, const float *vals_host,
                                            uint32_t *rowIdxs_out_host, uint32_t *colIdxs_out_host,

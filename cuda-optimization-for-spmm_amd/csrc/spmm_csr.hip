@@ -475,6 +475,7 @@ struct CsrArgs {
     float *C;
     uint32_t ldc;
     uint32_t nnz = 0;
+    const uint32_t *spans = nullptr;  // kernel 6 only: the rows as (row, start, end, 0), longest first
 };
 
 template <int G, int VEC, class Acc>
@@ -528,9 +529,9 @@ template <class Acc, int WAVES, int NB>
 static void launch_split_as(const CsrArgs &a) {
     const SplitTiling t = split_tiling(a.M, a.N, WAVES);
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
-    note_kernel("csr_split<W%d,R%d,%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), t.p, t.q);
+    note_kernel("csr_split<W%d,R%d,%s%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), a.spans ? ",longest-first" : "", t.p, t.q);
     hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream, a.M, a.rowPtrs,
-                       a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q, t.rows_per_part);
+                       a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q, t.rows_per_part, a.spans);
 }
 
 // one wave per row x 32 columns, the row's entries dealt over its 8 lane groups (csr_split.hpp).  GL7d25, us REFERENCE /
@@ -664,6 +665,27 @@ extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     const int vec = pick_vec(B, ldb, C, ldc, N);
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_csr<AccRefWide>(a, kernel, vec);
     else launch_csr<AccFast>(a, kernel, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+// Kernel 6 with the rows handed over longest first (spans from mispmm_csr_spans_by_length_host, uploaded by the caller).
+extern "C" int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                    const uint32_t *colIdxs, const float *vals, const uint32_t *spans, const float *B, uint32_t N,
+                                    uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_split: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!rowPtrs && !spans) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: rowPtrs and spans are both null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "csr_split: B of 2 GiB or more: use mispmm_csr_f32");
+    if (pick_vec(B, ldb, C, ldc, N) != 4)
+        return fail(MISPMM_ERR_UNSUPPORTED, "csr_split: B and C rows must be 16-byte vectors (N, ldb, ldc multiples of 4, aligned): use mispmm_csr_f32");
+    CsrArgs a{as_stream(stream), M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, nnz};
+    a.spans = spans;
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_split<AccRefWide>(a);
+    else launch_split<AccFast>(a);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

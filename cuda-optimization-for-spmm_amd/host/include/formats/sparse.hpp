@@ -20,6 +20,9 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     // > 0 on a device copy whose rows all hold exactly this many entries (checked on the host by
     // copy2Device): lets the wrapper take mispmm_csr_uniform_f32, which never reads rowPtrs
     MT uniformRowNnz = 0;
+    // device copies made by copy2Device() of a long-row matrix (24 entries per row or more on average) only: the rows as
+    // (row, start, end, 0), longest first -- what mispmm_csr_split_f32 walks so that the long rows start first
+    MT *rowSpans = nullptr;
 
     SparseMatrixCSR() = default;
     explicit SparseMatrixCSR(std::string filePath);

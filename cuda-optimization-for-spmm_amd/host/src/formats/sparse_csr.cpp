@@ -29,6 +29,7 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT>::~SparseMatrixCSR() 
     releaseBuffer(this->rowPtrs, this->onDevice);
     releaseBuffer(this->colIdxs, this->onDevice);
     releaseBuffer(this->data, this->onDevice);
+    releaseBuffer(this->rowSpans, this->onDevice);
 }
 
 template <typename DT, typename MT> bool SparseMatrixCSR<DT, MT>::allocateSpace(bool onDevice) {
@@ -51,6 +52,14 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     bool uniform = w > 0 && this->rowPtrs[0] == 0;
     for (size_t r = 0; uniform && r <= this->numRows; ++r) uniform = this->rowPtrs[r] == (MT)(r * w);
     d->uniformRowNnz = uniform ? w : 0;
+    // long rows: the split kernel wants them longest first (one counting sort per upload)
+    if (this->numRows && this->numNonZero / this->numRows >= 24) {
+        MT *spans = allocateBuffer<MT>((size_t)this->numRows * 4, false);
+        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, spans));
+        d->rowSpans = allocateBuffer<MT>((size_t)this->numRows * 4, true);
+        copyBuffer(d->rowSpans, true, spans, false, (size_t)this->numRows * 4 * sizeof(MT));
+        releaseBuffer(spans, false);
+    }
     return d;
 }
 

@@ -46,6 +46,15 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
                                                       b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;  // a B of 2 GiB or more falls through to the general call
             }
+            // long rows (spans built by copy2Device): kernel 6, and the library's own choice where it would split, with the
+            // rows longest first
+            const bool splits = kernelNum == 6 || ((kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5) &&
+                                                   (acc == MISPMM_ACC_FAST || b->numCols < 384));
+            if (a->rowSpans && splits) {
+                const int st = mispmm_csr_split_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data,
+                                                    a->rowSpans, b->data, b->numCols, b->numCols, c, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;  // rows that are not 16-byte vectors take the general call
+            }
             return mispmm_csr_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data, b->data,
                                   b->numCols, b->numCols, c, ldc, kernelNum, acc);
         });

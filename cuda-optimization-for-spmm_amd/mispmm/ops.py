@@ -50,6 +50,17 @@ def uniform_row_nnz(row_ptrs):
     return w if w > 0 and np.array_equal(rp, np.arange(rp.shape[0], dtype=np.int64) * w) else 0
 
 
+def csr_spans_by_length(row_ptrs):
+    """The rows as (row, start, end, 0) uint32 quadruples, longest first (mispmm_csr_spans_by_length_host): what
+    mispmm_csr_split_f32 walks so that the long rows start first."""
+    rp = np.ascontiguousarray(row_ptrs, dtype=np.uint32)
+    m = rp.shape[0] - 1
+    spans = np.zeros((max(m, 0), 4), dtype=np.uint32)
+    if m > 0:
+        capi.check(capi.lib().mispmm_csr_spans_by_length_host(m, rp.ctypes.data, spans.ctypes.data))
+    return spans
+
+
 @dataclass
 class DeviceCSR:
     num_rows: int
@@ -59,11 +70,17 @@ class DeviceCSR:
     col_idxs: torch.Tensor
     data: torch.Tensor
     uniform_row_nnz: int = 0     # > 0: structure hint checked on the host when A was uploaded
+    spans: torch.Tensor = None   # rows longest first, for the split kernel; built at upload for long-row matrices
 
     @staticmethod
-    def from_host(csr, device="cuda"):
+    def from_host(csr, device="cuda", spans=None):
+        """spans: True / False to build the longest-first row list or not; None = when the mean row holds 24 entries or
+        more (where the library's kernel 0 takes the split kernel)."""
+        if spans is None:
+            spans = csr.num_rows > 0 and csr.nnz // csr.num_rows >= 24
+        sp = _dev_u32(csr_spans_by_length(csr.row_ptrs).reshape(-1), device) if spans else None
         return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
-                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs))
+                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp)
 
 
 @dataclass
@@ -128,7 +145,8 @@ def _out(m, n, b, out):
 def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=True):
     """C = A @ B.  a: DeviceCSR, b: [K, N] float32 device tensor (row-major, any row stride).
     With the default kernel (0 / 5) a CSR whose rows all have the same length goes through
-    mispmm_csr_uniform_f32 (no row-pointer fetch); use_hint=False forces the general entry point."""
+    mispmm_csr_uniform_f32 (no row-pointer fetch), one that carries `spans` (long rows) through mispmm_csr_split_f32 with
+    its rows longest first; use_hint=False forces the general entry point."""
     _require_gpu(a.row_ptrs, b)
     if b.shape[0] != a.num_cols:
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
@@ -139,6 +157,16 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
                                                      _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c),
                                                      _dense_ld(c), capi.ACC_MODES[acc]))
         return c
+    # the split kernel with the rows longest first: kernel 6 always, kernel 0 / 5 where the library itself would split
+    # (REFERENCE mode: up to 383 columns)
+    wants_split = int(kernel) == 6 or (int(kernel) in (0, 5) and (acc == "fast" or n < 384))
+    if use_hint and os.environ.get("MISPMM_NO_HINT") != "1" and a.spans is not None and wants_split:
+        st = capi.lib().mispmm_csr_split_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),
+                                             _p(a.data), _p(a.spans), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
+                                             capi.ACC_MODES[acc])
+        if st != capi.ERR_UNSUPPORTED:  # operands that are not 16-byte vectors take the general entry point below
+            capi.check(st)
+            return c
     capi.check(capi.lib().mispmm_csr_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs),
                                          _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
                                          int(kernel), capi.ACC_MODES[acc]))

@@ -186,3 +186,29 @@ def test_bsr_nonzero_list_is_in_the_reference_order_of_addition():
     assert np.array_equal(rp, csr.row_ptrs) and np.array_equal(ci, csr.col_idxs) and np.array_equal(va, csr.data)
     assert l.mispmm_bsr_nonzeros_host(*head, rp.ctypes.data, None, None) == capi.ERR_INVALID_ARG
     assert l.mispmm_bsr_nonzeros_f32(None, 4, 4, 1, None, None, None, None, 8, 8, None, 8, 0) == capi.ERR_INVALID_ARG
+
+
+def test_csr_spans_are_the_rows_longest_first():
+    """mispmm_csr_spans_by_length_host: (row, start, end, 0) per row, decreasing length, ties in row order; the entry
+    point that walks them validates its arguments before touching a device."""
+    from mispmm import ops
+    l = capi.lib()
+    for name in ("GL7d25", "tols4000", "Hamrle1"):
+        csr = datasets.load_csr(name)
+        spans = ops.csr_spans_by_length(csr.row_ptrs)
+        lens = np.diff(csr.row_ptrs.astype(np.int64))
+        order = np.argsort(-lens, kind="stable")
+        assert np.array_equal(spans[:, 0], order)
+        assert np.array_equal(spans[:, 1], csr.row_ptrs[order]) and np.array_equal(spans[:, 2], csr.row_ptrs[order + 1])
+        assert not spans[:, 3].any()
+    assert ops.csr_spans_by_length(np.zeros(1, np.uint32)).shape == (0, 4)
+    bad = np.array([0, 3, 2], np.uint32)
+    out = np.zeros(8, np.uint32)
+    assert l.mispmm_csr_spans_by_length_host(2, bad.ctypes.data, out.ctypes.data) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_spans_by_length_host(2, None, out.ctypes.data) == capi.ERR_INVALID_ARG
+    one = ctypes.c_void_p(16)
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, None, one, one, None, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG   # no rows at all
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 8, one, 8, 7) == capi.ERR_INVALID_ARG    # accumulate mode
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 4, one, 8, 0) == capi.ERR_INVALID_ARG    # ldb < N
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 6, 6, one, 6, 0) == capi.ERR_UNSUPPORTED    # 8-byte rows
+    assert l.mispmm_csr_split_f32(None, 0, 4, 0, None, None, None, None, None, 8, 8, None, 8, 0) == capi.OK            # empty product

@@ -152,6 +152,24 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
+    """GL7d25 (rows of up to 422 entries, sorted so that the long ones come last) through `cuspmm --csr -k 128`: every
+    kernel agrees with the CPU engine; copy2Device builds the longest-first row list and kernel 6 / the library's own
+    choice run at more than twice the rate of the wave-per-row kernels (kept: 7.1 us = 0.227; floor a fifth under it)."""
+    from mispmm import datasets, formats
+    d = tmp_path / "GL7d25"
+    d.mkdir()
+    formats.write_csr(d / "GL7d25.csr", datasets.load_csr("GL7d25", dtype=np.float64), integer=True)
+    p = run_cli("--csr", "-k", "128", "--iters", "200", "-d", str(d))
+    recs = [r for r, _ in records(p.stdout)]
+    assert [r["kernelType"] for r in recs] == ["0", "1", "2", "3", "4", "5", "6", "-1"]
+    assert all(r["correct"] == "1" for r in recs)
+    frac = {r["kernelType"]: float(r["rooflineFrac"]) for r in recs if "rooflineFrac" in r}
+    assert frac["6"] >= 0.18 and frac["5"] >= 0.18, frac
+    assert max(frac[k] for k in ("1", "2", "3", "4")) < frac["6"], frac
+
+
+@pytest.mark.gpu
 def test_bench_line_perf_floors():
     """bench.py at the driver's flags: the headline and the ELL K=256 configuration must stay within a few percent of
     the kept numbers (profiles/r2/bench_*.json: 0.59-0.60 and 0.64-0.65 of the 8 TB/s roofline), and the line must

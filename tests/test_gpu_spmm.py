@@ -240,15 +240,33 @@ def test_csr_split_row_kernel(oracle, n):
 
 
 def test_csr_split_row_kernel_on_real_matrices(oracle):
-    """GL7d25 (mean 29, longest 422 entries; integer coefficients) and tols4000 (mean 2, longest 90) through kernel 6."""
+    """GL7d25 (mean 29, longest 422 entries; integer coefficients), tols4000 (mean 2, longest 90) and the headline
+    matrix through kernel 6, in row order (mispmm_csr_f32) and with the rows longest first (mispmm_csr_split_f32 + the
+    spans built at upload): the order decides when a row runs, never what it returns."""
     for name in ("GL7d25", "tols4000", "n4c6-b13"):
         csr = datasets.load_csr(name)
-        a = ops.DeviceCSR.from_host(csr)
-        for n in (128, 256):
+        a = ops.DeviceCSR.from_host(csr, spans=True)
+        assert (ops.DeviceCSR.from_host(csr).spans is not None) == (name == "GL7d25")   # built unasked for long rows only
+        for n in (32, 128, 256, 516):
             b = synth.dense_b(csr.num_cols, n)
             ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
             assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6, use_hint=False).cpu().numpy(), ref), (name, n)
-            assert "csr_split" in capi.last_kernel()
+            assert "csr_split" in capi.last_kernel() and "longest-first" not in capi.last_kernel()
+            assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6).cpu().numpy(), ref), (name, n)
+            assert "longest-first" in capi.last_kernel()
+            fast = ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy()
+            assert_fast_close(fast, ref, abs_scale(csr, b))
+        # rows that are not 16-byte vectors: the entry point declines, the general one takes over
+        b = synth.dense_b(csr.num_cols, 30)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6).cpu().numpy(), ref)
+        assert "csr_split" not in capi.last_kernel()
+    # kernel 0 on a long-row matrix takes the same path unasked
+    csr = datasets.load_csr("GL7d25")
+    a = ops.DeviceCSR.from_host(csr)
+    b = synth.dense_b(csr.num_cols, 128)
+    assert np.array_equal(ops.spmm_csr(a, dev(b)).cpu().numpy(), oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b))
+    assert "longest-first" in capi.last_kernel()
 
 
 def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tmp_path):

@@ -55,9 +55,11 @@ def main():
             c = torch.empty((csr.num_rows, n), device="cuda")
             want = ops.spmm_csr(a, b, kernel=1)
             alg = datasets.csr_algorithmic_bytes(csr, n)
-            for kernel in (5, 6):
+            if a.spans is None:
+                a = ops.DeviceCSR.from_host(csr, spans=True)
+            for kernel, hint in ((5, False), (6, False), (6, True)):   # hint: kernel 6 takes the rows longest first
                 for acc in ("reference", "fast"):
-                    st = timer.measure(lambda: ops.spmm_csr(a, b, out=c, kernel=kernel, acc=acc, stream=stream, use_hint=False), 100,
+                    st = timer.measure(lambda: ops.spmm_csr(a, b, out=c, kernel=kernel, acc=acc, stream=stream, use_hint=hint), 100,
                                        rounds=3, precondition_s=0.01)
                     stream.synchronize()
                     rec = {"matrix": name, "n": n, "kernel": kernel, "acc": acc, "us": round(st["median_us"], 3),
