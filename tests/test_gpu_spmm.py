@@ -269,6 +269,55 @@ def test_csr_split_row_kernel_on_real_matrices(oracle):
     assert "longest-first" in capi.last_kernel()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_csr_split_row_kernel_random_shapes(oracle, seed):
+    """Seeded sweep of kernel 6, in row order and longest first: row-length distributions (constant, geometric, a few
+    giants among short rows, sorted either way, empty stretches), matrix and dense widths, value distributions of A and B
+    (narrow, wide, sparse B, integers) -- REFERENCE mode must return the oracle's bits every time, FAST within its bound."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(8):
+        m = int(rng.integers(1, 700))
+        k = int(rng.integers(8, 3000))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            lens = np.full(m, int(rng.integers(0, min(k, 70))))
+        elif kind == 1:
+            lens = np.minimum(rng.geometric(1.0 / rng.integers(2, 60), m), k)
+        elif kind == 2:
+            lens = rng.integers(0, 6, m)
+            lens[rng.integers(0, m, max(1, m // 40))] = rng.integers(min(k, 100), min(k, 1200) + 1, max(1, m // 40))
+        elif kind == 3:
+            lens = np.sort(np.minimum(rng.geometric(1.0 / 30, m), k))[:: int(rng.choice([-1, 1]))]
+        else:
+            lens = np.where(rng.random(m) < 0.5, 0, rng.integers(1, min(k, 300) + 1, m))
+        lens = np.minimum(lens, k)
+        csr = random_csr(m, k, lens, seed=int(rng.integers(1 << 30)))
+        vals = csr.data
+        a_kind = int(rng.integers(0, 3))
+        if a_kind == 1:
+            vals = (vals * np.exp2(rng.integers(-20, 21, vals.shape))).astype(np.float32)
+        elif a_kind == 2:
+            vals = rng.integers(-24, 25, vals.shape).astype(np.float32)
+        csr = formats.CSR(m, k, csr.row_ptrs, csr.col_idxs, vals)
+        n = int(rng.choice([4, 8, 28, 32, 36, 64, 100, 128, 132, 256, 260, 384, 512]))
+        b = synth.dense_b(k, n, seed=int(rng.integers(1 << 20)))
+        b_kind = int(rng.integers(0, 4))
+        if b_kind == 1:
+            b = (b * np.exp2(rng.integers(-30, 31, b.shape))).astype(np.float32)
+        elif b_kind == 2:
+            b = np.where(rng.random(b.shape) < 0.7, np.float32(0), b)
+        elif b_kind == 3:
+            b = synth.dense_b(k, n, mode="exact")
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        a = ops.DeviceCSR.from_host(csr, spans=True)
+        what = (seed, case, m, k, kind, a_kind, n, b_kind)
+        assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6, use_hint=False).cpu().numpy(), ref), what
+        assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6).cpu().numpy(), ref), what
+        assert "longest-first" in capi.last_kernel()
+        with np.errstate(all="ignore"):
+            assert_fast_close(ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+
+
 def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tmp_path):
     """The measurement build counts the waves of kernel 6 that summed their row again in entry order: none on grid
     data, a handful on uniform data (products 2^19.. apart in rows of hundreds of entries), every wave with entries
