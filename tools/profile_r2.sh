@@ -45,7 +45,8 @@ rm -rf "$OUT/trace"
 pmc_pass() {  # <dir tag> <bench args> -- <counters...>
   local tag=$1; shift
   local args=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$tag" -- python3 bench.py $args --launch eager > "$OUT/$tag.json" 2> "$OUT/$tag.err" || echo "pmc pass $tag failed" >> "$OUT/pmc_errors.txt"
+  echo "pmc pass $tag: $*"
+  timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$tag" -- python3 bench.py $args --launch eager > "$OUT/$tag.json" 2> "$OUT/$tag.err" || echo "pmc pass $tag failed" | tee -a "$OUT/pmc_errors.txt"
 }
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr GRBM_GUI_ACTIVE"; do
