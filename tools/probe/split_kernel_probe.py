@@ -1,6 +1,11 @@
 """Kernel 6 (csr_split: one workgroup per row, the row dealt over its lane groups) against kernel 5 (lane-group row
 gather, or the deep wave-per-row kernel with MISPMM_SPLIT=0 in the tuning build) on the matrices with long or uneven
-rows, several dense widths; checks REFERENCE-mode bits against kernel 1 while it is at it."""
+rows, several dense widths; checks REFERENCE-mode bits against kernel 1 while it is at it.  Kernel 6 runs twice: in row
+order (mispmm_csr_f32) and with the rows longest first (mispmm_csr_split_f32).
+  usage: split_kernel_probe.py [matrix,matrix,..] [n,n,..]
+  PROBE_B_MODE = uniform (default) | exact (2^-8 grid) | clamped (no product small enough to fail the re-association
+                 test) | planted (exactly one element fails it) | wide (every wave fails it)
+  PROBE_CUT_ROWS = L: every row longer than L becomes several rows of at most L entries (timing experiment)"""
 import json
 import os
 import sys
