@@ -677,6 +677,7 @@ extern "C" int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t
         return fail(MISPMM_ERR_INVALID_ARG, "csr_split: unknown accumulate mode %d", acc_mode);
     if (M == 0 || N == 0) return MISPMM_OK;
     if (!rowPtrs && !spans) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: rowPtrs and spans are both null");
+    if (!aligned16(spans)) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: spans must be 16-byte aligned");
     if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: colIdxs or vals is null");
     if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
     if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "csr_split: B of 2 GiB or more: use mispmm_csr_f32");

@@ -211,4 +211,5 @@ def test_csr_spans_are_the_rows_longest_first():
     assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 8, one, 8, 7) == capi.ERR_INVALID_ARG    # accumulate mode
     assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 4, one, 8, 0) == capi.ERR_INVALID_ARG    # ldb < N
     assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 6, 6, one, 6, 0) == capi.ERR_UNSUPPORTED    # 8-byte rows
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, ctypes.c_void_p(24), one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG  # spans alignment
     assert l.mispmm_csr_split_f32(None, 0, 4, 0, None, None, None, None, None, 8, 8, None, 8, 0) == capi.OK            # empty product
