@@ -57,19 +57,25 @@ __device__ unsigned long long mispmm_split_stats[2];
 
 struct SplitTiling {
     uint32_t p, q;           // row parts x column parts over the XCDs, p * q == 8
-    uint32_t rows_per_part;  // ceil(M / p)
+    uint32_t rows_per_part;  // rows of a row part, ceil(M / p); with a span list: its workgroups
     uint32_t grid_x, grid_y;
 };
 
-inline SplitTiling split_tiling(uint32_t M, uint32_t N, uint32_t waves) {
+// M: rows, or -- with a span list -- its positions, dealt to the row parts in groups of `waves` (one workgroup each)
+inline SplitTiling split_tiling(uint32_t M, uint32_t N, uint32_t waves, bool spans) {
     const uint32_t colparts = ceil_div(N, 32u);
     uint32_t q = 1;
     while (q < 8u && q < colparts) q <<= 1;
     SplitTiling t;
     t.q = q;
     t.p = 8u / q;
-    t.rows_per_part = ceil_div(M, t.p);
-    t.grid_x = 8u * ceil_div(t.rows_per_part, waves);  // a multiple of 8: workgroup id % 8 == blockIdx.x % 8 in every grid row
+    if (spans) {
+        t.rows_per_part = ceil_div(ceil_div(M, waves), t.p);  // workgroups per row part
+        t.grid_x = 8u * t.rows_per_part;
+    } else {
+        t.rows_per_part = ceil_div(M, t.p);
+        t.grid_x = 8u * ceil_div(t.rows_per_part, waves);
+    }  // a multiple of 8: workgroup id % 8 == blockIdx.x % 8 in every grid row
     t.grid_y = ceil_div(colparts, q);
     return t;
 }
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     constexpr int OWN = 8;        // entries per step = lane groups = partial sums per output element
     constexpr int COLS = 32;
     constexpr int RING = NB * 4;  // B-segment reads in flight per lane, refilled in blocks of 4 steps
-    constexpr int PHASE = 512;    // entries staged in LDS at a time
+    constexpr int PHASE = 256;    // entries staged in LDS at a time
     static_assert(PHASE % (RING * OWN) == 0, "staging is padded to whole rings");
     // per wave: the staged entries | the partial sums (8 groups x 32 columns), reused by the ordered re-sum as the list
     // of the products of two steps (16 entries x 32 columns, fp32)
@@ -103,15 +109,16 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     // Placement only: any dispatch order gives the same result.
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t part_row = xcd / tile_q, part_col = xcd % tile_q;
-    const uint32_t local = (blockIdx.x >> 3) * WAVES + wave;
     // Without spans: row part k is the k-th contiguous range of rows, walked in row order.  With spans -- the rows as
-    // (row, start, end, 0) sorted by decreasing length, built once per matrix on the host -- row part k takes the
-    // positions k, k + P, .. of that order: the longest rows start first and every XCD gets an equal share of them.
-    // (GL7d25 is sorted the other way round, every row longer than 128 entries among its last 93: in row order they all
-    // start last and decide when the kernel ends.)
-    const uint32_t position = spans ? local * (8u / tile_q) + part_row : part_row * rows_per_part + local;
+    // (row, start, end, info) sorted by decreasing length, built once per matrix on the host -- the groups of WAVES
+    // positions (one workgroup each) are dealt to the row parts in turn: the longest rows start first and every XCD gets
+    // an equal share of them.  (GL7d25 is sorted the other way round, every row longer than 128 entries among its last
+    // 93: in row order they all start last and decide when the kernel ends.)
+    const uint32_t block = blockIdx.x >> 3;
+    const uint32_t position = spans ? (block * (8u / tile_q) + part_row) * WAVES + wave : part_row * rows_per_part + block * WAVES + wave;
     const uint32_t slab = (blockIdx.y * tile_q + part_col) * COLS;
-    if (local >= rows_per_part || position >= M || slab >= N) return;  // wave-uniform; there is no workgroup barrier below
+    // wave-uniform; the one workgroup barrier below is reached by the 4 waves of a shared row, which are all valid
+    if ((spans ? block : block * WAVES + wave) >= rows_per_part || position >= M || slab >= N) return;
     const uint32_t li = lane % G;
     const uint32_t group = lane / G;
     const uint32_t col0 = slab + li * 4u;
@@ -119,12 +126,14 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     const rsrc_t rsrc = make_rsrc(B, b_bytes);
     const uint32_t ldb4 = ldb * 4u;
     uint32_t row, start, end;
+    bool shared = false;  // this wave holds one of the WAVES chunks of a long row (workgroup-uniform)
     if (spans) {  // kernel-uniform
         using u4 = uint32_t __attribute__((ext_vector_type(4)));
         const u4 span = *reinterpret_cast<const u4 *>(spans + static_cast<size_t>(position) * 4u);
         row = __builtin_amdgcn_readfirstlane(span[0]);
         start = __builtin_amdgcn_readfirstlane(span[1]);
         end = __builtin_amdgcn_readfirstlane(span[2]);
+        shared = __builtin_amdgcn_readfirstlane(span[3]) != 0u;
     } else {
         row = position;
         start = __builtin_amdgcn_readfirstlane(rowPtrs[row]);
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
 
     T acc[4] = {0, 0, 0, 0};
     ExactTrack track;
+    bool staged_whole = true;
     double ordered = 0;  // ordered re-sum: the running sum of column `lane` (lanes 0..31)
     // One pass over the row, entry i read by lane group i % 8 in step i / 8.  kOrdered == false: every group adds its
     // products to its own partial sums.  kOrdered == true: the products go through LDS and are added in entry order.
@@ -163,8 +173,8 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
             const uint32_t nring = (steps + RING - 1u) / RING;
             wave_sync();  // the previous phase / the partial sums have been read
             // (byte offset of the B row, coefficient); the padding up to whole rings is (dropped load, 0): exact no-ops.
-            // A row of one phase is still staged when the ordered pass comes round.
-            if (!kOrdered || end - start > static_cast<uint32_t>(PHASE)) {
+            // A row of one phase that this wave staged whole is still in the strip when the ordered pass comes round.
+            if (!kOrdered || end - start > static_cast<uint32_t>(PHASE) || !staged_whole) {
                 for (uint32_t i = lane; i < nring * (RING * OWN); i += 64u) {
                     u2 pair{kDropLoad, 0u};
                     if (i < n) {
@@ -267,24 +277,57 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     wave_sync();
     const bool mine = lane < COLS && slab + lane < N;
     T total = 0;
-    bool redo = false;
-    if (mine) {
+    float hi = 0.f;
+    uint32_t lo = 0xFFFFFFFFu;
+    if (lane < COLS) {
         total = part[lane];
 #pragma unroll
         for (int o = 1; o < OWN; ++o) total += part[o * COLS + lane];
         if constexpr (kRef) {
-            float hi = track_hi[lane / 4u];
-            uint32_t lo = track_lo[lane / 4u];
 #pragma unroll
-            for (int o = 1; o < OWN; ++o) {
+            for (int o = 0; o < OWN; ++o) {
                 hi = __builtin_fmaxf(hi, track_hi[o * G + lane / 4u]);
                 lo = min(lo, track_lo[o * G + lane / 4u]);
             }
-            // NaN products do not reach `hi` (fmax drops them) but do reach the sum
-            redo = !reassociation_is_exact(end - start, hi, lo) || total != total;
         }
     }
+    if (shared) {
+        // A long row as WAVES chunks, one per wave of this workgroup (the span list places them so): each wave hands its
+        // chunk's (sum, extremes, bounds) over in its own LDS region, and after the one barrier wave 0 adds the chunks in
+        // entry order -- the row that decides when the kernel ends takes a quarter of its memory round trips.
+        constexpr int kSums = 0, kHi = COLS * static_cast<int>(sizeof(T)), kLo = kHi + COLS * 4, kBounds = kLo + COLS * 4;
+        static_assert(kBounds + 8 <= kPartBytes, "the hand-over fits the partial-sum region");
+        wave_sync();  // the partial sums have been read
+        unsigned char *const hand = smem[wave] + kStripBytes;
+        if (lane < COLS) {
+            reinterpret_cast<T *>(hand + kSums)[lane] = total;
+            reinterpret_cast<float *>(hand + kHi)[lane] = hi;
+            reinterpret_cast<uint32_t *>(hand + kLo)[lane] = lo;
+        }
+        if (lane == 0) {
+            reinterpret_cast<uint32_t *>(hand + kBounds)[0] = start;
+            reinterpret_cast<uint32_t *>(hand + kBounds)[1] = end;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        total = 0;
+        hi = 0.f;
+        lo = 0xFFFFFFFFu;
+        if (lane < COLS) {
+            for (uint32_t w = 0; w < WAVES; ++w) {  // wave order = entry order of the chunks
+                const unsigned char *const from = smem[w] + kStripBytes;
+                total += reinterpret_cast<const T *>(from + kSums)[lane];  // 0 + x == x: the first term is exact
+                hi = __builtin_fmaxf(hi, reinterpret_cast<const float *>(from + kHi)[lane]);
+                lo = min(lo, reinterpret_cast<const uint32_t *>(from + kLo)[lane]);
+            }
+        }
+        // from here on `start, end` are the whole row: its length for the test, its entries for the ordered pass
+        end = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(smem[WAVES - 1] + kStripBytes + kBounds)[1]);
+        staged_whole = false;
+    }
     if constexpr (kRef) {
+        // NaN products do not reach `hi` (fmax drops them) but do reach the sum
+        const bool redo = mine && (!reassociation_is_exact(end - start, hi, lo) || total != total);
         if (__ballot(redo) != 0) {  // wave-uniform
 #ifdef MISPMM_TUNING
             if (lane == 0) atomicAdd(&mispmm_split_stats[0], 1ull);

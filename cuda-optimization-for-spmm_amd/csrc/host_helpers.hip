@@ -66,26 +66,54 @@ extern "C" int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs
     return MISPMM_OK;
 }
 
-// The rows of a CSR as (row, start, end, 0), longest first (ties in row order: a counting sort by length, stable).
-extern "C" int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t *spans_out_host) {
+// The span list mispmm_csr_split_f32 walks: rows longest first (ties in row order: a counting sort by length, stable).
+// A row of more than share_len entries becomes 4 chunk spans (row, start, end, 1) in one aligned group of 4 positions --
+// the 4 waves of one workgroup; chunk lengths are multiples of 8 (one step of the kernel) -- and these groups come first;
+// the other rows follow as (row, start, end, 0).
+extern "C" int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t share_len, uint32_t *count_out,
+                                               uint32_t *spans_out_host) {
+    if (!count_out) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: count_out is null");
+    *count_out = 0;
     if (M == 0) return MISPMM_OK;
-    if (!rowPtrs_host || !spans_out_host) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: null argument");
+    if (!rowPtrs_host) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: rowPtrs is null");
+    if (share_len == 0) share_len = 128;
     uint32_t longest = 0;
+    uint64_t shared_rows = 0;
     for (uint32_t r = 0; r < M; ++r) {
         if (rowPtrs_host[r + 1] < rowPtrs_host[r]) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: row pointers decrease at row %u", r);
-        longest = std::max(longest, rowPtrs_host[r + 1] - rowPtrs_host[r]);
+        const uint32_t len = rowPtrs_host[r + 1] - rowPtrs_host[r];
+        longest = std::max(longest, len);
+        shared_rows += len > share_len;
     }
-    // first position of every length in the descending order
+    const uint64_t count = static_cast<uint64_t>(M) + 3u * shared_rows;
+    if (count > 0xFFFFFFFFull) return fail(MISPMM_ERR_INVALID_ARG, "csr spans: more than 2^32 spans");
+    *count_out = static_cast<uint32_t>(count);
+    if (!spans_out_host) return MISPMM_OK;  // size query
+    // rank of every row in the descending order: first position of every length, then a stable fill
     std::vector<uint32_t> first(static_cast<size_t>(longest) + 2, 0);
     for (uint32_t r = 0; r < M; ++r) ++first[longest - (rowPtrs_host[r + 1] - rowPtrs_host[r]) + 1];
     for (size_t k = 1; k < first.size(); ++k) first[k] += first[k - 1];
+    // the shared rows are exactly the first `shared_rows` ranks (they are the longest): rank k < shared_rows -> group k,
+    // any other rank k -> position 4 * shared_rows + (k - shared_rows)
     for (uint32_t r = 0; r < M; ++r) {
-        const uint32_t len = rowPtrs_host[r + 1] - rowPtrs_host[r];
-        uint32_t *span = spans_out_host + static_cast<size_t>(first[longest - len]++) * 4u;
-        span[0] = r;
-        span[1] = rowPtrs_host[r];
-        span[2] = rowPtrs_host[r + 1];
-        span[3] = 0;
+        const uint32_t s = rowPtrs_host[r], e = rowPtrs_host[r + 1], len = e - s;
+        const uint64_t rank = first[longest - len]++;
+        if (len > share_len) {
+            const uint32_t chunk = ((len + 3u) / 4u + 7u) & ~7u;
+            for (uint32_t k = 0; k < 4; ++k) {
+                uint32_t *span = spans_out_host + (rank * 4u + k) * 4u;
+                span[0] = r;
+                span[1] = std::min(e, s + k * chunk);
+                span[2] = std::min(e, s + (k + 1u) * chunk);
+                span[3] = 1;
+            }
+        } else {
+            uint32_t *span = spans_out_host + (4u * shared_rows + (rank - shared_rows)) * 4u;
+            span[0] = r;
+            span[1] = s;
+            span[2] = e;
+            span[3] = 0;
+        }
     }
     return MISPMM_OK;
 }

@@ -475,7 +475,8 @@ struct CsrArgs {
     float *C;
     uint32_t ldc;
     uint32_t nnz = 0;
-    const uint32_t *spans = nullptr;  // kernel 6 only: the rows as (row, start, end, 0), longest first
+    const uint32_t *spans = nullptr;  // kernel 6 only: the span list (rows longest first, long rows as 4 chunks)
+    uint32_t numSpans = 0;
 };
 
 template <int G, int VEC, class Acc>
@@ -527,10 +528,11 @@ static void launch_wave_deep(const CsrArgs &a) {
 
 template <class Acc, int WAVES, int NB>
 static void launch_split_as(const CsrArgs &a) {
-    const SplitTiling t = split_tiling(a.M, a.N, WAVES);
+    const SplitTiling t = split_tiling(a.spans ? a.numSpans : a.M, a.N, WAVES, a.spans != nullptr);
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     note_kernel("csr_split<W%d,R%d,%s%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), a.spans ? ",longest-first" : "", t.p, t.q);
-    hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream, a.M, a.rowPtrs,
+    hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream,
+                       a.spans ? a.numSpans : a.M, a.rowPtrs,
                        a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q, t.rows_per_part, a.spans);
 }
 
@@ -555,13 +557,14 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
     static const int long_env = knob_int("MISPMM_LONGROWS", -1);
     const bool long_rows = long_env >= 0 ? long_env != 0 : (a.M != 0 && a.nnz / a.M >= 24);
     // kernel 6, and kernel 5 on long rows: the row split over the lane groups of a wave (csr_split.hpp); needs 16-byte
-    // B rows.  GL7d25 (mean 29, longest 422 entries), us at N = 64 / 128 / 256 / 512:
-    //   REFERENCE, no element needs the ordered re-sum   7.9 /  9.8 / 13.9 / 28.1
-    //   REFERENCE, every wave re-sums (B spread over 2^60) 14.2 / 17.3 / 23.8 / 43.4
-    //   REFERENCE before (deep wave / lane group)       13.9 / 17.4 / 27.5 / 30.8
-    //   FAST 5.3 / 6.8 / 10.0 / 22.5 (before: 15.2 at N = 128)
+    // B rows.  GL7d25 (mean 29, longest 422 entries), rows in order, us at N = 64 / 128 / 256 / 512:
+    //   REFERENCE, no element needs the ordered re-sum    7.6 /  9.9 / 13.7 / 26.3
+    //   REFERENCE, every wave re-sums (B spread over 2^60) 15.1 / 18.6 / 24.7 / 42.6
+    //   REFERENCE before (deep wave / lane group)        13.9 / 17.4 / 27.5 / 30.8
+    //   FAST 5.7 / 7.0 / 10.0 / 21.4 (before: 15.2 at N = 128)
     // so REFERENCE mode keeps the lane-group kernel from N = 384 on, where the bad case costs more than the good one
-    // gains.  MISPMM_SPLIT=0 keeps kernel 5 off the split kernel altogether (measurement aid).
+    // gains.  (With the span list of mispmm_csr_split_f32: 4.7 / 6.9 / 11.2 / 24.2, worst case 10.3 / 10.6 / 18.0 / 37.0,
+    // FAST 3.9 / 5.5 / 8.8 / 20.0.)  MISPMM_SPLIT=0 keeps kernel 5 off the split kernel altogether (measurement aid).
     static const int split_env = knob_int("MISPMM_SPLIT", 1);
     const bool split_pays = std::is_same_v<Acc, AccFast> || a.N < 384;
     if (!wide && vec == 4 && (kernel == 6 || (kernel == 5 && long_rows && split_env != 0 && split_pays))) {
@@ -669,15 +672,18 @@ extern "C" int mispmm_csr_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     return MISPMM_OK;
 }
 
-// Kernel 6 with the rows handed over longest first (spans from mispmm_csr_spans_by_length_host, uploaded by the caller).
+// Kernel 6 walking a span list (mispmm_csr_spans_by_length_host, uploaded by the caller): rows longest first, long rows
+// as 4 chunks on the 4 waves of one workgroup.
 extern "C" int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
-                                    const uint32_t *colIdxs, const float *vals, const uint32_t *spans, const float *B, uint32_t N,
-                                    uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
+                                    const uint32_t *colIdxs, const float *vals, const uint32_t *spans, uint32_t numSpans,
+                                    const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
     if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
         return fail(MISPMM_ERR_INVALID_ARG, "csr_split: unknown accumulate mode %d", acc_mode);
     if (M == 0 || N == 0) return MISPMM_OK;
     if (!rowPtrs && !spans) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: rowPtrs and spans are both null");
     if (!aligned16(spans)) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: spans must be 16-byte aligned");
+    if (spans && (numSpans < M || (numSpans - M) % 3u != 0))
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_split: %u spans cannot describe %u rows (M + 3 per shared row)", numSpans, M);
     if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_split: colIdxs or vals is null");
     if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
     if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "csr_split: B of 2 GiB or more: use mispmm_csr_f32");
@@ -685,6 +691,7 @@ extern "C" int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t
         return fail(MISPMM_ERR_UNSUPPORTED, "csr_split: B and C rows must be 16-byte vectors (N, ldb, ldc multiples of 4, aligned): use mispmm_csr_f32");
     CsrArgs a{as_stream(stream), M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, nnz};
     a.spans = spans;
+    a.numSpans = numSpans;
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_split<AccRefWide>(a);
     else launch_split<AccFast>(a);
     MISPMM_LAUNCH_CHECK();

@@ -20,9 +20,10 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     // > 0 on a device copy whose rows all hold exactly this many entries (checked on the host by
     // copy2Device): lets the wrapper take mispmm_csr_uniform_f32, which never reads rowPtrs
     MT uniformRowNnz = 0;
-    // device copies made by copy2Device() of a long-row matrix (24 entries per row or more on average) only: the rows as
-    // (row, start, end, 0), longest first -- what mispmm_csr_split_f32 walks so that the long rows start first
+    // device copies made by copy2Device() of a long-row matrix (24 entries per row or more on average) only: the span
+    // list mispmm_csr_split_f32 walks -- rows longest first, the longest as 4 chunks each (mispmm_csr_spans_by_length_host)
     MT *rowSpans = nullptr;
+    MT numSpans = 0;
 
     SparseMatrixCSR() = default;
     explicit SparseMatrixCSR(std::string filePath);

@@ -54,10 +54,13 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     d->uniformRowNnz = uniform ? w : 0;
     // long rows: the split kernel wants them longest first (one counting sort per upload)
     if (this->numRows && this->numNonZero / this->numRows >= 24) {
-        MT *spans = allocateBuffer<MT>((size_t)this->numRows * 4, false);
-        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, spans));
-        d->rowSpans = allocateBuffer<MT>((size_t)this->numRows * 4, true);
-        copyBuffer(d->rowSpans, true, spans, false, (size_t)this->numRows * 4 * sizeof(MT));
+        uint32_t count = 0;
+        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, 0, &count, nullptr));
+        MT *spans = allocateBuffer<MT>((size_t)count * 4, false);
+        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, 0, &count, spans));
+        d->rowSpans = allocateBuffer<MT>((size_t)count * 4, true);
+        copyBuffer(d->rowSpans, true, spans, false, (size_t)count * 4 * sizeof(MT));
+        d->numSpans = count;
         releaseBuffer(spans, false);
     }
     return d;

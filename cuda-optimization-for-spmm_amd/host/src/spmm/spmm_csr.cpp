@@ -52,7 +52,7 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
                                                    (acc == MISPMM_ACC_FAST || b->numCols < 384));
             if (a->rowSpans && splits) {
                 const int st = mispmm_csr_split_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data,
-                                                    a->rowSpans, b->data, b->numCols, b->numCols, c, ldc, acc);
+                                                    a->rowSpans, a->numSpans, b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;  // rows that are not 16-byte vectors take the general call
             }
             return mispmm_csr_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data, b->data,

@@ -54,8 +54,8 @@ SIGNATURES = {
     "mispmm_csr_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_csr_uniform_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_batch_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),
-    "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
-    "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _vp]),
+    "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
+    "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32), _vp]),
     "mispmm_ell_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_ell_colmajor_to_rowmajor_host": (_i, [_u32, _u32, _u32, _vp, _vp, _c.POINTER(_u32), _vp, _vp]),
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),

@@ -50,14 +50,17 @@ def uniform_row_nnz(row_ptrs):
     return w if w > 0 and np.array_equal(rp, np.arange(rp.shape[0], dtype=np.int64) * w) else 0
 
 
-def csr_spans_by_length(row_ptrs):
-    """The rows as (row, start, end, 0) uint32 quadruples, longest first (mispmm_csr_spans_by_length_host): what
-    mispmm_csr_split_f32 walks so that the long rows start first."""
+def csr_spans_by_length(row_ptrs, share_len=0):
+    """The span list mispmm_csr_split_f32 walks (mispmm_csr_spans_by_length_host): [count, 4] uint32, the rows as
+    (row, start, end, 0) longest first, preceded by the rows of more than share_len entries (0 = 128) as 4 chunks
+    (row, start, end, 1) each."""
     rp = np.ascontiguousarray(row_ptrs, dtype=np.uint32)
-    m = rp.shape[0] - 1
-    spans = np.zeros((max(m, 0), 4), dtype=np.uint32)
-    if m > 0:
-        capi.check(capi.lib().mispmm_csr_spans_by_length_host(m, rp.ctypes.data, spans.ctypes.data))
+    m = max(rp.shape[0] - 1, 0)
+    count = ctypes.c_uint32(0)
+    capi.check(capi.lib().mispmm_csr_spans_by_length_host(m, rp.ctypes.data, int(share_len), ctypes.byref(count), None))
+    spans = np.zeros((count.value, 4), dtype=np.uint32)
+    if count.value:
+        capi.check(capi.lib().mispmm_csr_spans_by_length_host(m, rp.ctypes.data, int(share_len), ctypes.byref(count), spans.ctypes.data))
     return spans
 
 
@@ -73,12 +76,13 @@ class DeviceCSR:
     spans: torch.Tensor = None   # rows longest first, for the split kernel; built at upload for long-row matrices
 
     @staticmethod
-    def from_host(csr, device="cuda", spans=None):
-        """spans: True / False to build the longest-first row list or not; None = when the mean row holds 24 entries or
-        more (where the library's kernel 0 takes the split kernel)."""
+    def from_host(csr, device="cuda", spans=None, share_len=0):
+        """spans: True / False to build the span list of the split kernel or not; None = when the mean row holds 24 entries
+        or more (where the library's kernel 0 takes the split kernel).  share_len: rows longer than this are dealt to the 4
+        waves of a workgroup (0 = the library's default, 128)."""
         if spans is None:
             spans = csr.num_rows > 0 and csr.nnz // csr.num_rows >= 24
-        sp = _dev_u32(csr_spans_by_length(csr.row_ptrs).reshape(-1), device) if spans else None
+        sp = _dev_u32(csr_spans_by_length(csr.row_ptrs, share_len).reshape(-1), device) if spans else None
         return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
                          _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp)
 
@@ -162,8 +166,8 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
     wants_split = int(kernel) == 6 or (int(kernel) in (0, 5) and (acc == "fast" or n < 384))
     if use_hint and os.environ.get("MISPMM_NO_HINT") != "1" and a.spans is not None and wants_split:
         st = capi.lib().mispmm_csr_split_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),
-                                             _p(a.data), _p(a.spans), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
-                                             capi.ACC_MODES[acc])
+                                             _p(a.data), _p(a.spans), a.spans.numel() // 4, _p(b), n, _dense_ld(b), _p(c),
+                                             _dense_ld(c), capi.ACC_MODES[acc])
         if st != capi.ERR_UNSUPPORTED:  # operands that are not 16-byte vectors take the general entry point below
             capi.check(st)
             return c

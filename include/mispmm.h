@@ -146,19 +146,24 @@ int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint3
                            const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc,
                            int acc_mode);
 
-/* Kernel 6 with the rows taken LONGEST FIRST.  spans (device, 4 * M uint32, 16-byte aligned) lists the rows as
- * (row, rowPtrs[row], rowPtrs[row + 1], 0) sorted by decreasing length: mispmm_csr_spans_by_length_host builds the
- * list once per matrix (an O(M + longest) counting sort) and the caller uploads it, as the host layers do when A is
- * copied to the device.  Same arithmetic and results as mispmm_csr_f32 with kernel 6 (REFERENCE mode: the reference's
- * bits); the order only decides WHEN a row runs -- a matrix sorted by row length (GL7d25: every row of more than 128
- * entries among the last 93 of 2798) otherwise starts its long rows last.  spans may be NULL (row order; rowPtrs
- * needed), rowPtrs may be NULL when spans is given.  The caller vouches that spans describes this matrix.
+/* Kernel 6 walking a SPAN LIST instead of the rows in order.  spans (device, 4 * numSpans uint32, 16-byte aligned)
+ * is what mispmm_csr_spans_by_length_host builds once per matrix (an O(M + longest) counting sort; the host layers do it
+ * when A is copied to the device): the rows as (row, rowPtrs[row], rowPtrs[row + 1], 0) sorted by decreasing length,
+ * preceded by the rows of more than share_len entries (0 = 128) as 4 chunks (row, start, end, 1) each, one aligned group
+ * of 4 positions per row -- the 4 waves of one workgroup sum one chunk each and add the four in entry order.
+ * Same arithmetic and results as mispmm_csr_f32 with kernel 6 (REFERENCE mode: the reference's bits); the list only
+ * decides WHEN and by how many waves a row is summed -- a matrix sorted by row length (GL7d25: every row of more
+ * than 128 entries among the last 93 of 2798) otherwise starts its long rows last, and its longest row alone is as long
+ * as the rest of the kernel.  spans may be NULL (rows in order; rowPtrs needed, numSpans ignored); rowPtrs may be NULL
+ * when spans is given.  The caller vouches that the list describes this matrix.
  * Returns MISPMM_ERR_UNSUPPORTED (nothing launched) when B or C rows are not 16-byte vectors or B spans 2 GiB or
- * more: use mispmm_csr_f32.  New capability: the reference has no analysis phase. */
+ * more: use mispmm_csr_f32.  New capability: the reference has no analysis phase.
+ * mispmm_csr_spans_by_length_host: *count_out = number of spans (M + 3 per shared row); spans_out_host NULL = size query. */
 int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
-                         const uint32_t *colIdxs, const float *vals, const uint32_t *spans, const float *B, uint32_t N,
-                         uint32_t ldb, float *C, uint32_t ldc, int acc_mode);
-int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t *spans_out_host);
+                         const uint32_t *colIdxs, const float *vals, const uint32_t *spans, uint32_t numSpans, const float *B,
+                         uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int acc_mode);
+int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t share_len, uint32_t *count_out,
+                                    uint32_t *spans_out_host);
 
 /* Several products with the same A in ONE launch: C_list[i] = A * B_list[i], i < batch (HOST arrays of device
  * pointers; every operand N columns wide with leading dimensions ldb / ldc).  Same arithmetic and results as

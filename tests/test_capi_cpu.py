@@ -189,27 +189,43 @@ def test_bsr_nonzero_list_is_in_the_reference_order_of_addition():
 
 
 def test_csr_spans_are_the_rows_longest_first():
-    """mispmm_csr_spans_by_length_host: (row, start, end, 0) per row, decreasing length, ties in row order; the entry
-    point that walks them validates its arguments before touching a device."""
+    """mispmm_csr_spans_by_length_host: the rows of more than share_len entries first, 4 chunks (row, start, end, 1) each
+    that tile the row in whole steps of 8 entries (the last may be short, or empty); then (row, start, end, 0) per remaining row, decreasing length, ties in
+    row order.  The entry point that walks the list validates its arguments before touching a device."""
     from mispmm import ops
     l = capi.lib()
-    for name in ("GL7d25", "tols4000", "Hamrle1"):
+    for name, share in (("GL7d25", 0), ("GL7d25", 40), ("tols4000", 0), ("Hamrle1", 0), ("n4c6-b13", 13), ("GL7d25", 0xFFFFFFFF)):
         csr = datasets.load_csr(name)
-        spans = ops.csr_spans_by_length(csr.row_ptrs)
+        spans = ops.csr_spans_by_length(csr.row_ptrs, share)
         lens = np.diff(csr.row_ptrs.astype(np.int64))
+        limit = 128 if share == 0 else share
         order = np.argsort(-lens, kind="stable")
-        assert np.array_equal(spans[:, 0], order)
-        assert np.array_equal(spans[:, 1], csr.row_ptrs[order]) and np.array_equal(spans[:, 2], csr.row_ptrs[order + 1])
-        assert not spans[:, 3].any()
+        long_rows = order[lens[order] > limit]
+        assert spans.shape[0] == csr.num_rows + 3 * len(long_rows)
+        chunks, rest = spans[:4 * len(long_rows)].reshape(-1, 4, 4), spans[4 * len(long_rows):]
+        assert np.array_equal(chunks[:, :, 0], np.repeat(long_rows[:, None], 4, axis=1)) and (chunks[:, :, 3] == 1).all()
+        assert np.array_equal(chunks[:, 0, 1], csr.row_ptrs[long_rows]) and np.array_equal(chunks[:, 3, 2], csr.row_ptrs[long_rows + 1])
+        assert np.array_equal(chunks[:, 1:, 1], chunks[:, :-1, 2])                      # the chunks tile the row
+        clen = (chunks[:, :, 2] - chunks[:, :, 1]).astype(np.int64)
+        size = (((lens[long_rows] + 3) // 4 + 7) // 8 * 8)[:, None]                     # whole steps of 8 entries
+        assert (clen[:, 0] == size[:, 0]).all() and (clen <= size).all() and (clen >= 0).all()
+        assert ((clen == size) | (np.cumsum(clen, axis=1) == lens[long_rows][:, None])).all()   # full until the row ends
+        short = order[lens[order] <= limit]
+        assert np.array_equal(rest[:, 0], short) and not rest[:, 3].any()
+        assert np.array_equal(rest[:, 1], csr.row_ptrs[short]) and np.array_equal(rest[:, 2], csr.row_ptrs[short + 1])
     assert ops.csr_spans_by_length(np.zeros(1, np.uint32)).shape == (0, 4)
     bad = np.array([0, 3, 2], np.uint32)
-    out = np.zeros(8, np.uint32)
-    assert l.mispmm_csr_spans_by_length_host(2, bad.ctypes.data, out.ctypes.data) == capi.ERR_INVALID_ARG
-    assert l.mispmm_csr_spans_by_length_host(2, None, out.ctypes.data) == capi.ERR_INVALID_ARG
+    out = np.zeros(32, np.uint32)
+    count = ctypes.c_uint32(7)
+    assert l.mispmm_csr_spans_by_length_host(2, bad.ctypes.data, 0, ctypes.byref(count), out.ctypes.data) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_spans_by_length_host(2, None, 0, ctypes.byref(count), out.ctypes.data) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_spans_by_length_host(2, bad.ctypes.data, 0, None, out.ctypes.data) == capi.ERR_INVALID_ARG
     one = ctypes.c_void_p(16)
-    assert l.mispmm_csr_split_f32(None, 4, 4, 1, None, one, one, None, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG   # no rows at all
-    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 8, one, 8, 7) == capi.ERR_INVALID_ARG    # accumulate mode
-    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 8, 4, one, 8, 0) == capi.ERR_INVALID_ARG    # ldb < N
-    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, one, 6, 6, one, 6, 0) == capi.ERR_UNSUPPORTED    # 8-byte rows
-    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, ctypes.c_void_p(24), one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG  # spans alignment
-    assert l.mispmm_csr_split_f32(None, 0, 4, 0, None, None, None, None, None, 8, 8, None, 8, 0) == capi.OK            # empty product
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, None, one, one, None, 0, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG   # no rows at all
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, 0, one, 8, 8, one, 8, 7) == capi.ERR_INVALID_ARG    # accumulate mode
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, 0, one, 8, 4, one, 8, 0) == capi.ERR_INVALID_ARG    # ldb < N
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, None, 0, one, 6, 6, one, 6, 0) == capi.ERR_UNSUPPORTED    # 8-byte rows
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, ctypes.c_void_p(24), 4, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG  # alignment
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, one, 3, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG     # fewer spans than rows
+    assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, one, 6, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG     # not M + 3k
+    assert l.mispmm_csr_split_f32(None, 0, 4, 0, None, None, None, None, 0, None, 8, 8, None, 8, 0) == capi.OK            # empty product

@@ -155,7 +155,7 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
 def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
     """GL7d25 (rows of up to 422 entries, sorted so that the long ones come last) through `cuspmm --csr -k 128`: every
     kernel agrees with the CPU engine; copy2Device builds the longest-first row list and kernel 6 / the library's own
-    choice run at more than twice the rate of the wave-per-row kernels (kept: 7.1 us = 0.227; floor a fifth under it)."""
+    choice run at more than twice the rate of the wave-per-row kernels (kept: 6.9 us = 0.23; floor a fifth under it)."""
     from mispmm import datasets, formats
     d = tmp_path / "GL7d25"
     d.mkdir()

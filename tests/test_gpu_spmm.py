@@ -205,7 +205,7 @@ def test_csr_split_row_kernel(oracle, n):
     the fp32 limits -- and for rows of 0, 1, 7..9 entries, around the 512-entry LDS phase, 2500 entries."""
     lens = [0, 1, 7, 8, 9, 31, 32, 33, 511, 512, 513, 1025, 2500, 0, 64, 40, 25, 200, 422]
     csr = random_csr(len(lens), 3000, lens, seed=17)
-    a = ops.DeviceCSR.from_host(csr)
+    a = ops.DeviceCSR.from_host(csr, spans=False)      # the stateless entry point: rows in order
     b = synth.dense_b(csr.num_cols, n)
     rng = np.random.default_rng(5)
     wide = b * np.exp2(rng.integers(-30, 31, size=b.shape)).astype(np.float32)   # every long row fails the test
@@ -224,6 +224,13 @@ def test_csr_split_row_kernel(oracle, n):
         for kernel in (6, 0):
             c = ops.spmm_csr(a, dev(bb), kernel=kernel, acc="reference").cpu().numpy()
             assert np.array_equal(c, ref, equal_nan=True), (name, kernel, n)
+        # the same through the span list: rows of more than 128 (30) entries as 4 chunks on the waves of one workgroup
+        for share in (0, 30):
+            sp = ops.DeviceCSR.from_host(csr, spans=True, share_len=share)
+            c = ops.spmm_csr(sp, dev(bb), kernel=6, acc="reference").cpu().numpy()
+            assert np.array_equal(c, ref, equal_nan=True), (name, "spans", share, n)
+            assert "longest-first" in capi.last_kernel()
+    ops.spmm_csr(a, dev(b), kernel=0)
     assert ("csr_split" in capi.last_kernel()) == (n < 384)   # REFERENCE mode, kernel 0: the lane-group kernel from 384 on
     ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
     fast = ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy()
@@ -309,8 +316,9 @@ def test_csr_split_row_kernel_random_shapes(oracle, seed):
         elif b_kind == 3:
             b = synth.dense_b(k, n, mode="exact")
         ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
-        a = ops.DeviceCSR.from_host(csr, spans=True)
-        what = (seed, case, m, k, kind, a_kind, n, b_kind)
+        share = int(rng.choice([0, 8, 40, 300]))       # rows longer than this go to the 4 waves of a workgroup as chunks
+        a = ops.DeviceCSR.from_host(csr, spans=True, share_len=share)
+        what = (seed, case, m, k, kind, a_kind, n, b_kind, share)
         assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6, use_hint=False).cpu().numpy(), ref), what
         assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6).cpu().numpy(), ref), what
         assert "longest-first" in capi.last_kernel()
