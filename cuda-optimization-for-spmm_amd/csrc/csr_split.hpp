@@ -25,7 +25,13 @@
 // rows scatter over all of B (GL7d25: 29 entries per row over 21 074 columns) a workgroup-per-row variant reading
 // whole 512-byte B rows made every XCD fetch 4-8 MB against its 4 MB of L2, time proportional to N (N = 128 / 256:
 // 10.9 / 21.3 us FAST); this shape fetches 21 074 x 128 bytes per XCD, which fits (6.9 / 9.8 us).
-// Everything is wave-private (strip, partial sums, ordered re-sum): no workgroup barrier, a wave leaves when its row is done.
+// Everything is wave-private (strip, partial sums, ordered re-sum): a wave leaves when its row is done.
+//
+// Order: the stateless entry point walks the rows in row order.  mispmm_csr_split_f32 walks a span list built once per
+// matrix on the host -- rows by decreasing length, so the long ones start first (GL7d25 is sorted the other way round:
+// in row order its long rows all start last and decide when the kernel ends: 9.9 against 6.9 us), and every row of more
+// than 128 entries as 4 chunks on the 4 waves of one workgroup, which hand their chunk's sum and extremes over in LDS
+// (the kernel's one barrier) for wave 0 to add in entry order and test as a whole row.
 #pragma once
 #include "spmm_common.hpp"
 
