@@ -192,6 +192,12 @@ def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
     if outs is None:
         outs = [torch.empty((a.num_rows, n), dtype=torch.float32, device=bs[0].device) for _ in bs]
     ldc = _dense_ld(outs[0])
+    if a.spans is not None:
+        # long rows: the library issues one launch per operand anyway (there is no batched split kernel); go through the
+        # span list like spmm_csr does, so that both give the same bits in FAST mode as well
+        for b, c in zip(bs, outs):
+            spmm_csr(a, b, out=c, acc=acc, stream=stream)
+        return outs
     blist = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
     clist = (ctypes.c_void_p * len(bs))(*[c.data_ptr() for c in outs])
     capi.check(capi.lib().mispmm_csr_batch_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),

@@ -63,8 +63,11 @@ enum mispmm_status {
  *           AccT = double from src/main.cu:196);
  *      COO / ELL / BSR  fp32 product then fp32 add into C, in storage order
  *           (spmm_coo.cpp:16-24, spmm_ell.cpp:16-29, spmm_bsr.cpp:17-38).
- *  FAST: fp32 fused multiply-add chain in storage order (<= 1e-5 relative to
- *    sum|a||b| of the reference result; the MFMA kernels always use this). */
+ *  FAST: fp32 fused multiply-add chains (<= 1e-5 relative to sum|a||b| of the
+ *    reference result; the MFMA kernels always use this).  One chain per output
+ *    element in storage order, except CSR kernel 6, which adds 8 chains per row
+ *    (per chunk of a shared row) in a fixed order: run to run identical, but
+ *    not bit for bit what another kernel id or entry point returns. */
 enum mispmm_acc_mode { MISPMM_ACC_REFERENCE = 0, MISPMM_ACC_FAST = 1 };
 
 /* Kernel selector common to all formats: 0 lets the library choose. */
