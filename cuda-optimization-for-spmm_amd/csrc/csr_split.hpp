@@ -95,6 +95,10 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     using u2 = uint32_t __attribute__((ext_vector_type(2)));
     using T = typename Acc::T;
     constexpr bool kRef = std::is_same_v<Acc, AccRefWide>;
+    // COO / ELL / BSR arithmetic (fp32 product, fp32 add): no sum of theirs may be split, the row goes through the
+    // ordered pass straight away -- the same shape, order and reads in flight, one running fp32 sum per output element
+    constexpr bool kSequential = std::is_same_v<Acc, AccRefF32>;
+    using OrderedT = std::conditional_t<kSequential, float, double>;
     constexpr int G = 8;          // lanes per entry: 8 x 4 columns = one 128-byte segment of a B row
     constexpr int OWN = 8;        // entries per step = lane groups = partial sums per output element
     constexpr int COLS = 32;
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     T acc[4] = {0, 0, 0, 0};
     ExactTrack track;
     bool staged_whole = true;
-    double ordered = 0;  // ordered re-sum: the running sum of column `lane` (lanes 0..31)
+    OrderedT ordered = 0;  // ordered pass: the running sum of column `lane` (lanes 0..31)
     // One pass over the row, entry i read by lane group i % 8 in step i / 8.  kOrdered == false: every group adds its
     // products to its own partial sums.  kOrdered == true: the products go through LDS and are added in entry order.
     auto sweep = [&](auto ordered_tag) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
                             // past the row's end the products are +0.0 (dropped load x 0), and sum + 0.0 == sum: the
                             // running sum starts at +0.0 and so is never -0.0
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) ordered += static_cast<double>(term[k]);
+                            for (int k = 0; k < 16; ++k) ordered = ordered + static_cast<OrderedT>(term[k]);
                         }
                     }
                 } else {
@@ -270,6 +274,12 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
             });
         }
     };
+    if constexpr (kSequential) {
+        staged_whole = false;
+        sweep(std::true_type{});
+        if (lane < COLS && slab + lane < N) C[static_cast<size_t>(row) * ldc + slab + lane] = ordered;
+        return;
+    }
     sweep(std::false_type{});
 
     // partial sums -> LDS, then lanes 0..31 add their column's 8 partial sums in group order
@@ -343,6 +353,40 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
         }
     }
     if (mine) C[static_cast<size_t>(row) * ldc + slab + lane] = Acc::finish(total);
+}
+
+// ---- host side: what the CSR, COO and BSR-list entry points launch ---------------------------------------------------
+struct SplitArgs {
+    hipStream_t stream;
+    uint32_t M, K;
+    const uint32_t *rowPtrs, *colIdxs;
+    const float *vals, *B;
+    uint32_t N, ldb;
+    float *C;
+    uint32_t ldc;
+    const uint32_t *spans = nullptr;  // the span list (rows longest first, long rows as 4 chunks), or rows in order
+    uint32_t numSpans = 0;
+};
+
+template <class Acc, int WAVES, int NB>
+inline void launch_split_as(const SplitArgs &a) {
+    const SplitTiling t = split_tiling(a.spans ? a.numSpans : a.M, a.N, WAVES, a.spans != nullptr);
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
+    note_kernel("csr_split<W%d,R%d,%s%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), a.spans ? ",longest-first" : "", t.p, t.q);
+    hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream,
+                       a.spans ? a.numSpans : a.M, a.rowPtrs, a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q,
+                       t.rows_per_part, a.spans);
+}
+
+// one wave per row x 32 columns, the row's entries dealt over its 8 lane groups.  GL7d25, us REFERENCE / FAST at N = 128
+// with 4 / 8 / 16 reads in flight per lane: 10.4 / 6.8, 9.9 / 6.9, 12.2 / 9.5; 1, 2 or 4 waves per workgroup make no
+// difference.  Needs B and C rows of 16-byte vectors and a B below 2 GiB (the callers check).
+template <class Acc>
+inline void launch_split(const SplitArgs &a) {
+    static const int ring = knob_int("MISPMM_SPLIT_RING", 8);
+    if (ring == 4) launch_split_as<Acc, 4, 1>(a);
+    else if (ring == 16) launch_split_as<Acc, 4, 4>(a);
+    else launch_split_as<Acc, 4, 2>(a);
 }
 
 }  // namespace mispmm

@@ -9,6 +9,7 @@
 // rounding sequence of spmmCOOCpu, spmm_coo.cpp:16-24).  No atomics, deterministic.
 // Without a workspace each row group finds its range by binary search instead.
 #include "row_gather.hpp"
+#include "csr_split.hpp"
 
 namespace mispmm {
 
@@ -146,6 +147,22 @@ static void launch_coo_v(const CooArgs &a, int vec) {
     else launch_coo_g<1, Acc>(a, g);
 }
 
+// Rows with their boundaries materialised (prepared-bounds COO, the BSR non-zero list), fp32 arithmetic.  Long rows
+// (24 entries per row or more on average) of 16-byte B vectors take the split kernel's shape: one wave per row x 32
+// columns on the XCD column grid, 64 entries in flight -- summed in entry order in REFERENCE mode (fp32 product, fp32 add:
+// no re-association), split in FAST mode.  GL7d25 K=128 through the CLI: 20.6 -> 10.1 us (COO kernel 2, BSR kernel 3).
+template <class Acc>
+static void launch_rows(hipStream_t st, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs, const uint32_t *colIdxs,
+                        const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int vec) {
+    static const int split_env = knob_int("MISPMM_SPLIT", 1);
+    if (split_env != 0 && vec == 4 && M != 0 && nnz / M >= 24) {
+        launch_split<Acc>(SplitArgs{st, M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc});
+        return;
+    }
+    const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
+    launch_row_gather_auto<Acc>(ga, CsrRows{rowPtrs}, vec);
+}
+
 }  // namespace mispmm
 
 using namespace mispmm;
@@ -179,9 +196,8 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     const int vec = pick_vec(B, ldb, C, ldc, N);
     if (rowPtrs_workspace && static_cast<uint64_t>(K) * ldb * 4u <= 0x7FFFFFFFull) {
         // with its row bounds materialised a sorted COO is a CSR: same kernel, same order of sums
-        const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
-        if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefF32>(ga, CsrRows{rowPtrs_workspace}, vec);
-        else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs_workspace}, vec);
+        if (acc_mode == MISPMM_ACC_REFERENCE) launch_rows<AccRefF32>(st, M, K, nnz, rowPtrs_workspace, colIdxs, vals, B, N, ldb, C, ldc, vec);
+        else launch_rows<AccFast>(st, M, K, nnz, rowPtrs_workspace, colIdxs, vals, B, N, ldb, C, ldc, vec);
         MISPMM_LAUNCH_CHECK();
         return MISPMM_OK;
     }
@@ -205,10 +221,9 @@ extern "C" int mispmm_bsr_nonzeros_f32(mispmm_stream_t stream, uint32_t M, uint3
     if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
     if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
         return fail(MISPMM_ERR_UNSUPPORTED, "bsr_nonzeros: B of 2 GiB or more: use mispmm_bsr_f32");
-    const RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
     const int vec = pick_vec(B, ldb, C, ldc, N);
-    if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefF32>(ga, CsrRows{rowPtrs}, vec);
-    else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_rows<AccRefF32>(as_stream(stream), M, K, nnz, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, vec);
+    else launch_rows<AccFast>(as_stream(stream), M, K, nnz, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, vec);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

@@ -526,25 +526,13 @@ static void launch_wave_deep(const CsrArgs &a) {
                        b_bytes, a.N, a.ldb, a.C, a.ldc, xg.chunk);
 }
 
-template <class Acc, int WAVES, int NB>
-static void launch_split_as(const CsrArgs &a) {
-    const SplitTiling t = split_tiling(a.spans ? a.numSpans : a.M, a.N, WAVES, a.spans != nullptr);
-    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
-    note_kernel("csr_split<W%d,R%d,%s%s> xcd %ux%u", WAVES, NB * 4, acc_tag<Acc>(), a.spans ? ",longest-first" : "", t.p, t.q);
-    hipLaunchKernelGGL((csr_split<Acc, WAVES, NB>), dim3(t.grid_x, t.grid_y), dim3(WAVES * 64), 0, a.stream,
-                       a.spans ? a.numSpans : a.M, a.rowPtrs,
-                       a.colIdxs, a.vals, a.B, b_bytes, a.N, a.ldb, a.C, a.ldc, t.q, t.rows_per_part, a.spans);
-}
-
-// one wave per row x 32 columns, the row's entries dealt over its 8 lane groups (csr_split.hpp).  GL7d25, us REFERENCE /
-// FAST at N = 128 with 4 / 8 / 16 reads in flight per lane: 10.4 / 6.8, 9.9 / 6.9, 12.2 / 9.5; 1, 2 or 4 waves per
-// workgroup make no difference.
+// the split kernel (csr_split.hpp) on the arguments of a CSR call
 template <class Acc>
 static void launch_split(const CsrArgs &a) {
-    static const int ring = knob_int("MISPMM_SPLIT_RING", 8);
-    if (ring == 4) launch_split_as<Acc, 4, 1>(a);
-    else if (ring == 16) launch_split_as<Acc, 4, 4>(a);
-    else launch_split_as<Acc, 4, 2>(a);
+    SplitArgs sa{a.stream, a.M, a.K, a.rowPtrs, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc};
+    sa.spans = a.spans;
+    sa.numSpans = a.numSpans;
+    mispmm::launch_split<Acc>(sa);
 }
 
 template <class Acc>

@@ -538,6 +538,36 @@ def test_coo_matches_oracle(oracle, name, ns, workspace):
         assert_fast_close(ops.spmm_coo(a, dev(b), acc="fast", workspace=workspace).cpu().numpy(), ref, abs_scale(csr, b))
 
 
+@pytest.mark.parametrize("n", [32, 128, 260])
+def test_coo_and_bsr_list_long_rows_take_the_split_shape(oracle, n):
+    """A COO (prepared row bounds) / BSR non-zero list with 24 entries per row or more and 16-byte B rows runs on the
+    split kernel's shape -- wave per row x 32 columns, XCD column grid -- with its fp32 sums in entry order: the bits of
+    spmmCOOCpu / spmmBSRCpu, for rows of 0..2500 entries, products over 2^60, sparse B, and on GL7d25."""
+    lens = [0, 1, 7, 8, 9, 255, 256, 257, 513, 2500, 0, 64, 40, 25, 200, 422, 31, 33]
+    csr = random_csr(len(lens), 3000, lens, seed=23)
+    rng = np.random.default_rng(9)
+    b = synth.dense_b(csr.num_cols, n)
+    wide = b * np.exp2(rng.integers(-30, 31, size=b.shape)).astype(np.float32)
+    sparse_b = np.where(rng.random(b.shape) < 0.5, np.float32(0), b)
+    for mat in (csr, datasets.load_csr("GL7d25")):
+        coo = formats.csr_to_coo(mat)
+        a = ops.DeviceCOO.from_host(coo)
+        for bb in ((b, wide, sparse_b) if mat is csr else (synth.dense_b(mat.num_cols, n),)):
+            ref = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, bb)
+            assert np.array_equal(ops.spmm_coo(a, dev(bb)).cpu().numpy(), ref)
+            assert "csr_split" in capi.last_kernel() and "ref32" in capi.last_kernel()
+            fast = ops.spmm_coo(a, dev(bb), acc="fast").cpu().numpy()
+            assert_fast_close(fast, ref, abs_scale(mat, bb))
+            assert np.array_equal(ops.spmm_coo(a, dev(bb), workspace=False).cpu().numpy(), ref)      # binary-search kernel
+    gl = datasets.load_csr("GL7d25")
+    bsr = formats.csr_to_bsr(gl, 2)
+    nz = ops.bsr_nonzeros(bsr)
+    bb = synth.dense_b(gl.num_cols, n)
+    ref = oracle.spmm_bsr(bsr.num_rows, 2, 2, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, bb)
+    assert np.array_equal(ops.spmm_bsr_nonzeros(nz, dev(bb)).cpu().numpy(), ref)
+    assert "csr_split" in capi.last_kernel()
+
+
 def test_coo_with_empty_leading_and_trailing_rows(oracle):
     coo = formats.COO(9, 6, np.array([2, 2, 5, 5, 5, 6], np.uint32), np.array([0, 3, 1, 2, 5, 4], np.uint32),
                       np.array([1, -2, 3, 4, -5, 6], np.float32))
