@@ -45,6 +45,35 @@ extern "C" int mispmm_ell_colmajor_to_rowmajor_host(uint32_t numRows, uint32_t n
     return MISPMM_OK;
 }
 
+// The occupied slots of a row-major ELL as a row-pointer list, slot order kept.
+extern "C" int mispmm_ell_compact_host(uint32_t M, uint32_t width, const uint32_t *rmColIdxs_host, const float *rmVals_host,
+                                       uint32_t *nnz_out, uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host,
+                                       float *vals_out_host) {
+    if (!nnz_out) return fail(MISPMM_ERR_INVALID_ARG, "ell compact: nnz_out is null");
+    const size_t slots = static_cast<size_t>(M) * width;
+    if (slots != 0 && (!rmColIdxs_host || !rmVals_host)) return fail(MISPMM_ERR_INVALID_ARG, "ell compact: null input");
+    uint64_t count = 0;
+    for (size_t i = 0; i < slots; ++i) count += rmColIdxs_host[i] != 0xFFFFFFFFu;
+    if (count > 0xFFFFFFFFull) return fail(MISPMM_ERR_INVALID_ARG, "ell compact: more than 2^32 entries");
+    *nnz_out = static_cast<uint32_t>(count);
+    if (!rowPtrs_out_host && !colIdxs_out_host && !vals_out_host) return MISPMM_OK;  // size query
+    if (!rowPtrs_out_host || (count != 0 && (!colIdxs_out_host || !vals_out_host)))
+        return fail(MISPMM_ERR_INVALID_ARG, "ell compact: null output");
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < M; ++r) {
+        rowPtrs_out_host[r] = n;
+        for (uint32_t s = 0; s < width; ++s) {
+            const size_t i = static_cast<size_t>(r) * width + s;
+            if (rmColIdxs_host[i] == 0xFFFFFFFFu) continue;
+            colIdxs_out_host[n] = rmColIdxs_host[i];
+            vals_out_host[n] = rmVals_host[i];
+            ++n;
+        }
+    }
+    rowPtrs_out_host[M] = n;
+    return MISPMM_OK;
+}
+
 extern "C" int mispmm_shard_rows_by_nnz_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t parts,
                                              uint32_t *bounds_out_host) {
     if (parts == 0) return fail(MISPMM_ERR_INVALID_ARG, "shard: parts must be >= 1");

@@ -207,6 +207,25 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     return MISPMM_OK;
 }
 
+// An ELL without its padding is the same thing once more: rows with their boundaries, fp32 product and fp32 add in list order.
+extern "C" int mispmm_ell_compact_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                      const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb,
+                                      float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "ell_compact: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!rowPtrs) return fail(MISPMM_ERR_INVALID_ARG, "ell_compact: rowPtrs is null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "ell_compact: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "ell_compact: B of 2 GiB or more: use mispmm_ell_f32");
+    const int vec = pick_vec(B, ldb, C, ldc, N);
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_rows<AccRefF32>(as_stream(stream), M, K, nnz, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, vec);
+    else launch_rows<AccFast>(as_stream(stream), M, K, nnz, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
 // The zero-skipping BSR path: the block entries that are not zero, listed per C row in the reference's order of
 // addition (mispmm_bsr_nonzeros_host), are a CSR whose REFERENCE arithmetic is COO's (fp32 product, fp32 add), so
 // it runs on the same instantiations as the prepared-bounds COO kernel above.

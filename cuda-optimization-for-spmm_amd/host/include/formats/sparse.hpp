@@ -78,6 +78,12 @@ template <typename _dataT, typename _metaT> class SparseMatrixELL : public Spars
     MT *rmColIdxs = nullptr;
     DT *rmData = nullptr;
     MT rowWidth = 0;
+    // device only, built by copy2Device() when more than half of the slots are padding: the occupied slots per row in
+    // slot order (mispmm_ell_compact_host) -- what mispmm_ell_compact_f32 multiplies from
+    MT *cpRowPtrs = nullptr;
+    MT *cpColIdxs = nullptr;
+    DT *cpData = nullptr;
+    MT cpCount = 0;
 
     SparseMatrixELL() = default;
     // files `<name>_rowind.ell` (header "rows cols nnz maxColNnz") and `<name>_values_colmajor.ell`

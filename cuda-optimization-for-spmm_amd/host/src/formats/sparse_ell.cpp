@@ -41,6 +41,9 @@ template <typename DT, typename MT> SparseMatrixELL<DT, MT>::~SparseMatrixELL() 
     releaseBuffer(this->data, this->onDevice);
     releaseBuffer(this->rmColIdxs, true);
     releaseBuffer(this->rmData, true);
+    releaseBuffer(this->cpRowPtrs, true);
+    releaseBuffer(this->cpColIdxs, true);
+    releaseBuffer(this->cpData, true);
 }
 
 template <typename DT, typename MT> bool SparseMatrixELL<DT, MT>::allocateSpace(bool onDevice) {
@@ -73,6 +76,22 @@ template <typename DT, typename MT> SparseMatrixELL<DT, MT> *SparseMatrixELL<DT,
         d->rmData = allocateBuffer<DT>(n, true);
         copyBuffer(d->rmColIdxs, true, cols.data(), false, n * sizeof(MT));
         copyBuffer(d->rmData, true, vals.data(), false, n * sizeof(DT));
+        // mostly padding (an ELL is as wide as its longest row): also keep the list of occupied slots
+        uint32_t occupied = 0;
+        mispmmCheckError(mispmm_ell_compact_host(this->numRows, width, cols.data(), vals.data(), &occupied, nullptr, nullptr, nullptr));
+        if (n != 0 && (size_t)occupied * 2 < n) {
+            std::vector<uint32_t> rp((size_t)this->numRows + 1), ci(occupied ? occupied : 1);
+            std::vector<float> va(occupied ? occupied : 1);
+            mispmmCheckError(mispmm_ell_compact_host(this->numRows, width, cols.data(), vals.data(), &occupied, rp.data(), ci.data(),
+                                                     va.data()));
+            d->cpRowPtrs = allocateBuffer<MT>((size_t)this->numRows + 1, true);
+            d->cpColIdxs = allocateBuffer<MT>(ci.size(), true);
+            d->cpData = allocateBuffer<DT>(va.size(), true);
+            copyBuffer(d->cpRowPtrs, true, rp.data(), false, rp.size() * sizeof(MT));
+            copyBuffer(d->cpColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
+            copyBuffer(d->cpData, true, va.data(), false, va.size() * sizeof(DT));
+            d->cpCount = occupied;
+        }
     }
     return d;
 }

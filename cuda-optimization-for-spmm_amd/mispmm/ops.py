@@ -94,13 +94,29 @@ class DeviceELL:
     width: int
     col_idxs: torch.Tensor
     data: torch.Tensor
+    compact: tuple = None     # (nnz, rowPtrs, colIdxs, vals) of the occupied slots, when most of the ELL is padding
 
     @staticmethod
-    def from_host(ell, device="cuda"):
+    def from_host(ell, device="cuda", compact=None):
+        """compact: True / False to list the occupied slots (mispmm_ell_compact_host) or not; None = when more than half of
+        the slots are padding."""
         if isinstance(ell, formats.ELLColMajor):
             ell = colmajor_ell_to_rowmajor(ell)
+        cols = np.ascontiguousarray(ell.col_idxs, dtype=np.uint32).reshape(-1)
+        vals = np.ascontiguousarray(ell.data, dtype=np.float32).reshape(-1)
+        listed = None
+        if compact is None:
+            compact = cols.size > 0 and int(np.count_nonzero(cols == 0xFFFFFFFF)) * 2 > cols.size
+        if compact:
+            nnz = ctypes.c_uint32(0)
+            head = (ell.num_rows, ell.width, cols.ctypes.data, vals.ctypes.data, ctypes.byref(nnz))
+            capi.check(capi.lib().mispmm_ell_compact_host(*head, None, None, None))
+            rp = np.zeros(ell.num_rows + 1, np.uint32)
+            ci, va = np.zeros(max(nnz.value, 1), np.uint32), np.zeros(max(nnz.value, 1), np.float32)
+            capi.check(capi.lib().mispmm_ell_compact_host(*head, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+            listed = (nnz.value, _dev_u32(rp, device), _dev_u32(ci, device), _dev_f32(va, device))
         return DeviceELL(ell.num_rows, ell.num_cols, ell.width, _dev_u32(ell.col_idxs, device),
-                         _dev_f32(ell.data, device))
+                         _dev_f32(ell.data, device), listed)
 
 
 @dataclass
@@ -212,6 +228,13 @@ def spmm_ell(a, b, out=None, kernel=0, acc="reference", stream=None):
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
+    if a.compact is not None and int(kernel) in (0, 1):   # mostly padding: multiply from the list of occupied slots
+        nnz, rp, ci, va = a.compact
+        st = capi.lib().mispmm_ell_compact_f32(_stream_ptr(stream), a.num_rows, a.num_cols, nnz, _p(rp), _p(ci), _p(va), _p(b), n,
+                                               _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
+        if st != capi.ERR_UNSUPPORTED:
+            capi.check(st)
+            return c
     capi.check(capi.lib().mispmm_ell_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.width, _p(a.col_idxs),
                                          _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c), int(kernel),
                                          capi.ACC_MODES[acc]))

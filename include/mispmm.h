@@ -211,6 +211,20 @@ int mispmm_bsr_f32(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, ui
                    int acc_mode);
 #define MISPMM_BSR_NUM_KERNELS 2
 
+/* ELL without its padding.  An ELL is as wide as its longest row: GL7d25 (mean 29, longest 422 entries) is 93 %
+ * padding, ACTIVSg10K 81 %, and the padded kernel walks every slot.  The host helper lists the occupied slots of the
+ * row-major view as (rowPtrs[M+1], colIdxs, vals) in slot order -- the order spmmELLCpu adds them; a padding slot adds
+ * nothing there (`if (row >= 0)`, spmm_ell.cpp:21), so leaving it out changes no sum: call it with the three outputs
+ * NULL for *nnz_out, then with arrays of that size, once per upload (the host layers do when more than half of the
+ * slots are padding).  The device call multiplies from that list with ELL's arithmetic (REFERENCE = fp32 product, fp32
+ * add in list order; same bits as mispmm_ell_f32); rows of 24 entries or more on average take the split kernel's shape
+ * with ordered sums.  Returns MISPMM_ERR_UNSUPPORTED for a B of 2 GiB or more: use mispmm_ell_f32. */
+int mispmm_ell_compact_host(uint32_t M, uint32_t width, const uint32_t *rmColIdxs_host, const float *rmVals_host, uint32_t *nnz_out,
+                            uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host, float *vals_out_host);
+int mispmm_ell_compact_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                           const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
+                           uint32_t ldc, int acc_mode);
+
 /* Zero-skipping BSR.  At BSR-16 the SuiteSparse matrices of data/ are ~98 % explicit zeros (ACTIVSg10K: 33 100 blocks
  * for 137 736 non-zeros): the dense block arithmetic of mispmm_bsr_f32 kernel 1 spends 84 us where the non-zeros
  * need 7.  The host helper lists the block entries that are not zero as (rowPtrs[M+1], colIdxs, vals), per C row in

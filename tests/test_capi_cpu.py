@@ -229,3 +229,24 @@ def test_csr_spans_are_the_rows_longest_first():
     assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, one, 3, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG     # fewer spans than rows
     assert l.mispmm_csr_split_f32(None, 4, 4, 1, one, one, one, one, 6, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG     # not M + 3k
     assert l.mispmm_csr_split_f32(None, 0, 4, 0, None, None, None, None, 0, None, 8, 8, None, 8, 0) == capi.OK            # empty product
+
+
+def test_ell_compact_list_keeps_slot_order():
+    """mispmm_ell_compact_host: the slots that are not padding, per row, in slot order -- padding anywhere in a row."""
+    l = capi.lib()
+    pad = 0xFFFFFFFF
+    cols = np.array([[pad, 5, pad, 2], [pad, pad, pad, pad], [7, 1, 3, pad]], np.uint32)
+    vals = np.arange(12, dtype=np.float32).reshape(3, 4) + 1
+    nnz = ctypes.c_uint32(0)
+    head = (3, 4, cols.ctypes.data, vals.ctypes.data, ctypes.byref(nnz))
+    capi.check(l.mispmm_ell_compact_host(*head, None, None, None))
+    assert nnz.value == 5
+    rp, ci, va = np.zeros(4, np.uint32), np.zeros(5, np.uint32), np.zeros(5, np.float32)
+    capi.check(l.mispmm_ell_compact_host(*head, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
+    assert rp.tolist() == [0, 2, 2, 5] and ci.tolist() == [5, 2, 7, 1, 3] and va.tolist() == [2, 4, 9, 10, 11]
+    assert l.mispmm_ell_compact_host(*head, rp.ctypes.data, None, None) == capi.ERR_INVALID_ARG
+    assert l.mispmm_ell_compact_host(3, 4, None, vals.ctypes.data, ctypes.byref(nnz), None, None, None) == capi.ERR_INVALID_ARG
+    one = ctypes.c_void_p(16)
+    assert l.mispmm_ell_compact_f32(None, 4, 4, 1, None, one, one, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG
+    assert l.mispmm_ell_compact_f32(None, 4, 4, 1, one, one, one, one, 8, 8, one, 8, 5) == capi.ERR_INVALID_ARG
+    assert l.mispmm_ell_compact_f32(None, 0, 4, 0, None, None, None, None, 8, 8, None, 8, 0) == capi.OK

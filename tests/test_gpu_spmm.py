@@ -482,6 +482,25 @@ def test_ell_matches_oracle(oracle, name, ns):
             assert_fast_close(ops.spmm_ell(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
 
 
+def test_ell_mostly_padding_multiplies_from_the_occupied_slots(oracle):
+    """An ELL that is mostly padding (as wide as its longest row) carries the list of its occupied slots
+    (mispmm_ell_compact_*): same slot order, same bits as the padded kernel and as spmmELLCpu -- GL7d25 (93 % padding,
+    long rows: the split kernel's shape), ACTIVSg10K (81 %), a uniform ELL keeps the padded kernel."""
+    for name, n, listed, split in (("GL7d25", 128, True, True), ("ACTIVSg10K", 128, True, False), ("n4c6-b13", 64, False, False),
+                                   ("GL7d25", 30, True, False)):
+        csr = datasets.load_csr(name)
+        ell = formats.csr_to_ell_colmajor(csr)
+        a = ops.DeviceELL.from_host(ell)
+        assert (a.compact is not None) == listed
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_ell_colmajor(ell.num_rows, ell.row_idxs, ell.data, b)
+        assert np.array_equal(ops.spmm_ell(a, dev(b)).cpu().numpy(), ref), name
+        assert ("csr_split" in capi.last_kernel()) == split, capi.last_kernel()
+        padded = ops.DeviceELL.from_host(ell, compact=False)
+        assert np.array_equal(ops.spmm_ell(padded, dev(b)).cpu().numpy(), ref), name
+        assert_fast_close(ops.spmm_ell(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+
+
 def test_ell_padding_anywhere_and_wide_rows(oracle):
     rng = np.random.default_rng(5)
     m, k, w = 37, 500, 150
