@@ -153,10 +153,14 @@ static void launch_coo_v(const CooArgs &a, int vec) {
 // no re-association), split in FAST mode.  GL7d25 K=128 through the CLI: 20.6 -> 10.1 us (COO kernel 2, BSR kernel 3).
 template <class Acc>
 static void launch_rows(hipStream_t st, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs, const uint32_t *colIdxs,
-                        const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int vec) {
+                        const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int vec,
+                        const uint32_t *spans = nullptr) {
     static const int split_env = knob_int("MISPMM_SPLIT", 1);
-    if (split_env != 0 && vec == 4 && M != 0 && nnz / M >= 24) {
-        launch_split<Acc>(SplitArgs{st, M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc});
+    if (spans || (split_env != 0 && vec == 4 && M != 0 && nnz / M >= 24)) {
+        SplitArgs sa{st, M, K, rowPtrs, colIdxs, vals, B, N, ldb, C, ldc};
+        sa.spans = spans;
+        sa.numSpans = spans ? M : 0u;
+        launch_split<Acc>(sa);
         return;
     }
     const RowGatherArgs ga{st, M, K, colIdxs, vals, B, N, ldb, C, ldc, M ? nnz / M : 0u};
@@ -203,6 +207,27 @@ extern "C" int mispmm_coo_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, ui
     }
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_coo_v<AccRefF32>(a, vec);
     else launch_coo_v<AccFast>(a, vec);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+// Rows with the fp32 arithmetic of COO / ELL / BSR on the split kernel's shape, walked longest first: spans = one
+// (row, start, end, 0) per row from mispmm_csr_spans_by_length_host with share_len = 0xFFFFFFFF (a sum of this arithmetic
+// cannot be dealt to several waves).  What the host layers call for a long-row COO, ELL or BSR list.
+extern "C" int mispmm_rows_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs,
+                                     const float *vals, const uint32_t *spans, uint32_t numSpans, const float *B, uint32_t N,
+                                     uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "rows_split: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!spans || !aligned16(spans)) return fail(MISPMM_ERR_INVALID_ARG, "rows_split: spans is null or not 16-byte aligned");
+    if (numSpans != M) return fail(MISPMM_ERR_INVALID_ARG, "rows_split: %u spans for %u rows (one per row: share_len = 0xFFFFFFFF)", numSpans, M);
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "rows_split: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "rows_split: B of 2 GiB or more");
+    if (pick_vec(B, ldb, C, ldc, N) != 4) return fail(MISPMM_ERR_UNSUPPORTED, "rows_split: B and C rows must be 16-byte vectors");
+    if (acc_mode == MISPMM_ACC_REFERENCE) launch_rows<AccRefF32>(as_stream(stream), M, K, nnz, nullptr, colIdxs, vals, B, N, ldb, C, ldc, 4, spans);
+    else launch_rows<AccFast>(as_stream(stream), M, K, nnz, nullptr, colIdxs, vals, B, N, ldb, C, ldc, 4, spans);
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

@@ -8,6 +8,11 @@
 
 namespace cuspmm {
 
+// Device copy of the span list of a matrix whose rows are given by host row pointers (mispmm_csr_spans_by_length_host):
+// rows longest first; shareLen = 0 lets rows of more than 128 entries become 4 chunks (CSR arithmetic only),
+// 0xFFFFFFFF keeps one span per row (the fp32 arithmetic of COO / ELL / BSR).  Defined in sparse_csr.cpp.
+uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans);
+
 // ----------------------------------------------------------------------------------------------------
 // CSR matrix (/root/reference/include/formats/sparse_csr.hpp:11-39).
 // `.csr` text file: "rows cols nnz" / rowPtrs (rows + 1) / colIdxs / values, one line each.
@@ -50,6 +55,8 @@ template <typename _dataT, typename _metaT> class SparseMatrixCOO : public Spars
     // device only: (numRows + 1) scratch the COO kernel fills with row boundaries
     MT *rowBoundsWorkspace = nullptr;
     bool rowBoundsReady = false;  // set once the boundaries of this device copy have been written
+    // device only, for a COO of 24 entries per row or more: its rows as spans, longest first (mispmm_rows_split_f32)
+    MT *rowSpans = nullptr;
 
     SparseMatrixCOO() = default;
     explicit SparseMatrixCOO(std::string filePath);
@@ -84,6 +91,7 @@ template <typename _dataT, typename _metaT> class SparseMatrixELL : public Spars
     MT *cpColIdxs = nullptr;
     DT *cpData = nullptr;
     MT cpCount = 0;
+    MT *cpSpans = nullptr;  // ... and, from 24 occupied slots per row, its rows as spans, longest first
 
     SparseMatrixELL() = default;
     // files `<name>_rowind.ell` (header "rows cols nnz maxColNnz") and `<name>_values_colmajor.ell`
@@ -119,6 +127,7 @@ template <typename _dataT, typename _metaT> class SparseMatrixBSR : public Spars
     MT *nzColIdxs = nullptr;
     DT *nzVals = nullptr;
     MT nzCount = 0;
+    MT *nzSpans = nullptr;  // from 24 list entries per row: the list's rows as spans, longest first (mispmm_rows_split_f32)
 
     SparseMatrixBSR() = default;
     explicit SparseMatrixBSR(std::string filePath);

@@ -51,6 +51,7 @@ template <typename DT, typename MT> SparseMatrixBSR<DT, MT>::~SparseMatrixBSR() 
     releaseBuffer(this->blockColIdxs, this->onDevice);
     releaseBuffer(this->data, this->onDevice);
     releaseBuffer(this->nzRowPtrs, true);
+    releaseBuffer(this->nzSpans, true);
     releaseBuffer(this->nzColIdxs, true);
     releaseBuffer(this->nzVals, true);
 }
@@ -97,6 +98,10 @@ template <typename DT, typename MT> SparseMatrixBSR<DT, MT> *SparseMatrixBSR<DT,
         copyBuffer(d->nzRowPtrs, true, rp.data(), false, rp.size() * sizeof(MT));
         copyBuffer(d->nzColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
         copyBuffer(d->nzVals, true, va.data(), false, va.size() * sizeof(DT));
+        if (this->numRows && nz / this->numRows >= 24) {
+            uint32_t count = 0;
+            d->nzSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count);
+        }
     }
     return d;
 }

@@ -41,6 +41,18 @@ template <typename DT, typename MT> bool SparseMatrixCSR<DT, MT>::allocateSpace(
     return true;
 }
 
+uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans) {
+    uint32_t count = 0;
+    mispmmCheckError(mispmm_csr_spans_by_length_host(numRows, rowPtrsHost, shareLen, &count, nullptr));
+    uint32_t *spans = allocateBuffer<uint32_t>((size_t)count * 4, false);
+    mispmmCheckError(mispmm_csr_spans_by_length_host(numRows, rowPtrsHost, shareLen, &count, spans));
+    uint32_t *dev = allocateBuffer<uint32_t>((size_t)count * 4, true);
+    copyBuffer(dev, true, spans, false, (size_t)count * 4 * sizeof(uint32_t));
+    releaseBuffer(spans, false);
+    numSpans = count;
+    return dev;
+}
+
 template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT, MT>::copy2Device() {
     assert(!this->onDevice && this->rowPtrs != nullptr);
     auto *d = new SparseMatrixCSR<DT, MT>(this->numRows, this->numCols, this->numNonZero, true);
@@ -55,13 +67,8 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     // long rows: the split kernel wants them longest first (one counting sort per upload)
     if (this->numRows && this->numNonZero / this->numRows >= 24) {
         uint32_t count = 0;
-        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, 0, &count, nullptr));
-        MT *spans = allocateBuffer<MT>((size_t)count * 4, false);
-        mispmmCheckError(mispmm_csr_spans_by_length_host(this->numRows, this->rowPtrs, 0, &count, spans));
-        d->rowSpans = allocateBuffer<MT>((size_t)count * 4, true);
-        copyBuffer(d->rowSpans, true, spans, false, (size_t)count * 4 * sizeof(MT));
+        d->rowSpans = uploadRowSpans(this->numRows, this->rowPtrs, 0, count);
         d->numSpans = count;
-        releaseBuffer(spans, false);
     }
     return d;
 }

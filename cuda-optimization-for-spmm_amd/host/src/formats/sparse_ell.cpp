@@ -44,6 +44,7 @@ template <typename DT, typename MT> SparseMatrixELL<DT, MT>::~SparseMatrixELL() 
     releaseBuffer(this->cpRowPtrs, true);
     releaseBuffer(this->cpColIdxs, true);
     releaseBuffer(this->cpData, true);
+    releaseBuffer(this->cpSpans, true);
 }
 
 template <typename DT, typename MT> bool SparseMatrixELL<DT, MT>::allocateSpace(bool onDevice) {
@@ -91,6 +92,10 @@ template <typename DT, typename MT> SparseMatrixELL<DT, MT> *SparseMatrixELL<DT,
             copyBuffer(d->cpColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
             copyBuffer(d->cpData, true, va.data(), false, va.size() * sizeof(DT));
             d->cpCount = occupied;
+            if (occupied / this->numRows >= 24) {
+                uint32_t count = 0;
+                d->cpSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count);
+            }
         }
     }
     return d;

@@ -56,6 +56,11 @@ DenseMatrix<DT, MT> *spmmBSRWrapper(int kernelNum, SparseMatrixBSR<DT, MT> *a, D
             const WrapperShape nzShape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->nzCount * n,
                                        a->nzCount * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
             return runWrapper<DT, MT>(nzShape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+                if (a->nzSpans) {  // long rows: longest first
+                    const int st = mispmm_rows_split_f32(stream, a->numRows, a->numCols, a->nzCount, a->nzColIdxs, a->nzVals, a->nzSpans,
+                                                         a->numRows, b->data, b->numCols, b->numCols, c, ldc, acc);
+                    if (st != MISPMM_ERR_UNSUPPORTED) return st;
+                }
                 return mispmm_bsr_nonzeros_f32(stream, a->numRows, a->numCols, a->nzCount, a->nzRowPtrs, a->nzColIdxs, a->nzVals,
                                                b->data, b->numCols, b->numCols, c, ldc, acc);
             });

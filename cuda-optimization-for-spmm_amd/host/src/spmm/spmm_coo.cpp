@@ -43,6 +43,11 @@ DenseMatrix<DT, MT> *spmmCOOWrapper(int kernelNum, SparseMatrixCOO<DT, MT> *a, D
             a->rowBoundsReady = true;
         }
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            if (a->rowSpans) {  // long rows: the spans carry the row boundaries, and the rows run longest first
+                const int st = mispmm_rows_split_f32(stream, a->numRows, a->numCols, a->numNonZero, a->colIdxs, a->data, a->rowSpans,
+                                                     a->numRows, b->data, b->numCols, b->numCols, c, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;
+            }
             if (kernelNum == 1) a->rowBoundsReady = true;
             return mispmm_coo_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowIdxs, a->colIdxs, a->data, b->data,
                                   b->numCols, b->numCols, c, ldc, a->rowBoundsWorkspace, kernelNum, acc);

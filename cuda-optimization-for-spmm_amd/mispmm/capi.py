@@ -61,6 +61,7 @@ SIGNATURES = {
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_bsr_nonzeros_host": (_i, [_u32, _u32, _u32, _u32, _vp, _vp, _vp, _c.POINTER(_u32), _vp, _vp, _vp]),
     "mispmm_bsr_nonzeros_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
+    "mispmm_rows_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_ell_compact_host": (_i, [_u32, _u32, _vp, _vp, _c.POINTER(_u32), _vp, _vp, _vp]),
     "mispmm_ell_compact_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),

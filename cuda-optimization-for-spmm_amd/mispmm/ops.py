@@ -114,7 +114,7 @@ class DeviceELL:
             rp = np.zeros(ell.num_rows + 1, np.uint32)
             ci, va = np.zeros(max(nnz.value, 1), np.uint32), np.zeros(max(nnz.value, 1), np.float32)
             capi.check(capi.lib().mispmm_ell_compact_host(*head, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
-            listed = (nnz.value, _dev_u32(rp, device), _dev_u32(ci, device), _dev_f32(va, device))
+            listed = (nnz.value, _dev_u32(rp, device), _dev_u32(ci, device), _dev_f32(va, device), _row_spans(rp, device))
         return DeviceELL(ell.num_rows, ell.num_cols, ell.width, _dev_u32(ell.col_idxs, device),
                          _dev_f32(ell.data, device), listed)
 
@@ -137,6 +137,28 @@ class DeviceBSR:
                          _dev_f32(bsr.data.reshape(-1), device))
 
 
+def _row_spans(row_ptrs, device):
+    """One span per row, longest first (the fp32 arithmetic of COO / ELL / BSR cannot deal a row to several waves), for a
+    list of 24 entries per row or more; else None."""
+    rp = np.asarray(row_ptrs, dtype=np.int64)
+    m = rp.shape[0] - 1
+    if m <= 0 or int(rp[-1]) // m < 24:
+        return None
+    return _dev_u32(csr_spans_by_length(row_ptrs, 0xFFFFFFFF).reshape(-1), device)
+
+
+def _rows_split(spans, num_rows, num_cols, nnz, col_idxs, data, b, c, acc, stream):
+    """mispmm_rows_split_f32 if the operands allow it; False = take the format's own entry point."""
+    if spans is None:
+        return False
+    st = capi.lib().mispmm_rows_split_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(spans), num_rows,
+                                          _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
+    if st == capi.ERR_UNSUPPORTED:
+        return False
+    capi.check(st)
+    return True
+
+
 @dataclass
 class DeviceCOO:
     num_rows: int
@@ -145,12 +167,15 @@ class DeviceCOO:
     row_idxs: torch.Tensor
     col_idxs: torch.Tensor
     data: torch.Tensor
+    spans: torch.Tensor = None   # long rows: (row, start, end, 0) per row, longest first -- carries the row boundaries
 
     @staticmethod
     def from_host(coo, device="cuda"):
         order = np.lexsort((coo.col_idxs, coo.row_idxs))
-        return DeviceCOO(coo.num_rows, coo.num_cols, coo.nnz, _dev_u32(coo.row_idxs[order], device),
-                         _dev_u32(coo.col_idxs[order], device), _dev_f32(coo.data[order], device))
+        rows = np.asarray(coo.row_idxs)[order]
+        row_ptrs = np.searchsorted(rows, np.arange(coo.num_rows + 1)).astype(np.uint32)
+        return DeviceCOO(coo.num_rows, coo.num_cols, coo.nnz, _dev_u32(rows, device),
+                         _dev_u32(coo.col_idxs[order], device), _dev_f32(coo.data[order], device), _row_spans(row_ptrs, device))
 
 
 def _out(m, n, b, out):
@@ -229,7 +254,9 @@ def spmm_ell(a, b, out=None, kernel=0, acc="reference", stream=None):
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
     if a.compact is not None and int(kernel) in (0, 1):   # mostly padding: multiply from the list of occupied slots
-        nnz, rp, ci, va = a.compact
+        nnz, rp, ci, va, spans = a.compact
+        if _rows_split(spans, a.num_rows, a.num_cols, nnz, ci, va, b, c, acc, stream):
+            return c
         st = capi.lib().mispmm_ell_compact_f32(_stream_ptr(stream), a.num_rows, a.num_cols, nnz, _p(rp), _p(ci), _p(va), _p(b), n,
                                                _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
         if st != capi.ERR_UNSUPPORTED:
@@ -270,7 +297,7 @@ def bsr_nonzeros(bsr, device="cuda"):
     va = np.empty(max(1, nnz.value), dtype=np.float32)
     capi.check(l.mispmm_bsr_nonzeros_host(*args, rp.ctypes.data, ci.ctypes.data, va.ctypes.data))
     return DeviceCSR(bsr.num_rows, bsr.num_cols, nnz.value, _dev_u32(rp, device), _dev_u32(ci[:nnz.value], device),
-                     _dev_f32(va[:nnz.value], device), 0)
+                     _dev_f32(va[:nnz.value], device), 0, _row_spans(rp, device))
 
 
 def spmm_bsr_nonzeros(nz, b, out=None, acc="reference", stream=None):
@@ -280,6 +307,8 @@ def spmm_bsr_nonzeros(nz, b, out=None, acc="reference", stream=None):
         raise ValueError(f"B has {b.shape[0]} rows, A has {nz.num_cols} columns")
     n = b.shape[1]
     c = _out(nz.num_rows, n, b, out)
+    if _rows_split(nz.spans, nz.num_rows, nz.num_cols, nz.nnz, nz.col_idxs, nz.data, b, c, acc, stream):
+        return c
     capi.check(capi.lib().mispmm_bsr_nonzeros_f32(_stream_ptr(stream), nz.num_rows, nz.num_cols, nz.nnz, _p(nz.row_ptrs),
                                                   _p(nz.col_idxs), _p(nz.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
                                                   capi.ACC_MODES[acc]))
@@ -306,6 +335,8 @@ def spmm_coo(a, b, out=None, kernel=0, acc="reference", stream=None, workspace=T
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
+    if workspace is not False and int(kernel) in (0, 1, 2) and _rows_split(a.spans, a.num_rows, a.num_cols, a.nnz, a.col_idxs, a.data, b, c, acc, stream):
+        return c
     capi.check(capi.lib().mispmm_coo_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_idxs),
                                          _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
                                          _p(ws), int(kernel), capi.ACC_MODES[acc]))

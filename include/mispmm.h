@@ -225,6 +225,17 @@ int mispmm_ell_compact_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint3
                            const uint32_t *colIdxs, const float *vals, const float *B, uint32_t N, uint32_t ldb, float *C,
                            uint32_t ldc, int acc_mode);
 
+/* Rows with the fp32 arithmetic of COO / ELL / BSR (fp32 product, fp32 add in list order) on the split kernel's shape,
+ * walked LONGEST FIRST.  spans (device, 4 * M uint32, 16-byte aligned) = mispmm_csr_spans_by_length_host with
+ * share_len = 0xFFFFFFFF: one (row, start, end, 0) per row -- a sum of this arithmetic cannot be dealt to several
+ * waves -- built once per upload from the row pointers of a sorted COO, of the BSR non-zero list or of the compact ELL.
+ * Same bits as mispmm_coo_f32 / mispmm_ell_compact_f32 / mispmm_bsr_nonzeros_f32; the row boundaries are in the spans,
+ * so a COO needs no boundary pass.  MISPMM_ERR_UNSUPPORTED when B or C rows are not 16-byte vectors or B spans
+ * 2 GiB or more: use the format's own entry point. */
+int mispmm_rows_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
+                          const uint32_t *spans, uint32_t numSpans, const float *B, uint32_t N, uint32_t ldb, float *C,
+                          uint32_t ldc, int acc_mode);
+
 /* Zero-skipping BSR.  At BSR-16 the SuiteSparse matrices of data/ are ~98 % explicit zeros (ACTIVSg10K: 33 100 blocks
  * for 137 736 non-zeros): the dense block arithmetic of mispmm_bsr_f32 kernel 1 spends 84 us where the non-zeros
  * need 7.  The host helper lists the block entries that are not zero as (rowPtrs[M+1], colIdxs, vals), per C row in

@@ -250,3 +250,16 @@ def test_ell_compact_list_keeps_slot_order():
     assert l.mispmm_ell_compact_f32(None, 4, 4, 1, None, one, one, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG
     assert l.mispmm_ell_compact_f32(None, 4, 4, 1, one, one, one, one, 8, 8, one, 8, 5) == capi.ERR_INVALID_ARG
     assert l.mispmm_ell_compact_f32(None, 0, 4, 0, None, None, None, None, 8, 8, None, 8, 0) == capi.OK
+
+
+def test_rows_split_entry_validates_its_span_list():
+    """mispmm_rows_split_f32 takes one span per row (the fp32 arithmetic cannot deal a row to several waves)."""
+    l = capi.lib()
+    one = ctypes.c_void_p(16)
+    args = lambda spans, count, n=8, ld=8, acc=0: (None, 4, 4, 1, one, one, spans, count, one, n, ld, one, ld, acc)   # noqa: E731
+    assert l.mispmm_rows_split_f32(*args(None, 4)) == capi.ERR_INVALID_ARG                    # no spans
+    assert l.mispmm_rows_split_f32(*args(ctypes.c_void_p(24), 4)) == capi.ERR_INVALID_ARG    # alignment
+    assert l.mispmm_rows_split_f32(*args(one, 7)) == capi.ERR_INVALID_ARG                     # a chunked list
+    assert l.mispmm_rows_split_f32(*args(one, 4, acc=3)) == capi.ERR_INVALID_ARG
+    assert l.mispmm_rows_split_f32(*args(one, 4, n=6, ld=6)) == capi.ERR_UNSUPPORTED          # 8-byte rows
+    assert l.mispmm_rows_split_f32(None, 0, 4, 0, None, None, None, 0, None, 8, 8, None, 8, 0) == capi.OK

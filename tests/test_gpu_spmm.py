@@ -574,7 +574,11 @@ def test_coo_and_bsr_list_long_rows_take_the_split_shape(oracle, n):
         for bb in ((b, wide, sparse_b) if mat is csr else (synth.dense_b(mat.num_cols, n),)):
             ref = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, bb)
             assert np.array_equal(ops.spmm_coo(a, dev(bb)).cpu().numpy(), ref)
-            assert "csr_split" in capi.last_kernel() and "ref32" in capi.last_kernel()
+            assert "csr_split" in capi.last_kernel() and "ref32,longest-first" in capi.last_kernel()   # spans built at upload
+            ws = ops.coo_row_bounds(a)
+            assert np.array_equal(ops.spmm_coo(ops.DeviceCOO(a.num_rows, a.num_cols, a.nnz, a.row_idxs, a.col_idxs, a.data), dev(bb),
+                                               workspace=ws, kernel=2).cpu().numpy(), ref)                  # no spans: rows in order
+            assert "csr_split" in capi.last_kernel() and "longest-first" not in capi.last_kernel()
             fast = ops.spmm_coo(a, dev(bb), acc="fast").cpu().numpy()
             assert_fast_close(fast, ref, abs_scale(mat, bb))
             assert np.array_equal(ops.spmm_coo(a, dev(bb), workspace=False).cpu().numpy(), ref)      # binary-search kernel
@@ -584,7 +588,7 @@ def test_coo_and_bsr_list_long_rows_take_the_split_shape(oracle, n):
     bb = synth.dense_b(gl.num_cols, n)
     ref = oracle.spmm_bsr(bsr.num_rows, 2, 2, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, bb)
     assert np.array_equal(ops.spmm_bsr_nonzeros(nz, dev(bb)).cpu().numpy(), ref)
-    assert "csr_split" in capi.last_kernel()
+    assert "csr_split" in capi.last_kernel() and "longest-first" in capi.last_kernel()
 
 
 def test_coo_with_empty_leading_and_trailing_rows(oracle):
