@@ -307,6 +307,7 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
             }
         }
     }
+    bool need_ordered = false;
     if (shared) {
         // A long row as WAVES chunks, one per wave of this workgroup (the span list places them so): each wave hands its
         // chunk's (sum, extremes, bounds) over in its own LDS region, and after the one barrier wave 0 adds the chunks in
@@ -326,25 +327,56 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
         }
         __syncthreads();
         if (wave != 0) return;
+        // Chunk by chunk: as long as the union of the chunks so far passes the test, their sum is exact whatever the
+        // order -- it IS the reference's running sum at that point -- so the ordered pass, if one is needed, starts at the
+        // first chunk that breaks the test, from that sum, instead of at the row's first entry.
         total = 0;
         hi = 0.f;
         lo = 0xFFFFFFFFu;
-        if (lane < COLS) {
-            for (uint32_t w = 0; w < WAVES; ++w) {  // wave order = entry order of the chunks
-                const unsigned char *const from = smem[w] + kStripBytes;
-                total += reinterpret_cast<const T *>(from + kSums)[lane];  // 0 + x == x: the first term is exact
-                hi = __builtin_fmaxf(hi, reinterpret_cast<const float *>(from + kHi)[lane]);
-                lo = min(lo, reinterpret_cast<const uint32_t *>(from + kLo)[lane]);
+        bool broken = false;
+        uint32_t resume = start;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {  // wave order = entry order of the chunks
+            const unsigned char *const from = smem[w] + kStripBytes;
+            const uint32_t chunk_start = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(from + kBounds)[0]);
+            const uint32_t chunk_end = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(from + kBounds)[1]);
+            if (!broken) {  // wave-uniform
+                T sum = total;
+                float h = hi;
+                uint32_t l = lo;
+                if (lane < COLS) {
+                    sum += reinterpret_cast<const T *>(from + kSums)[lane];  // 0 + x == x: the first term is exact
+                    h = __builtin_fmaxf(h, reinterpret_cast<const float *>(from + kHi)[lane]);
+                    l = min(l, reinterpret_cast<const uint32_t *>(from + kLo)[lane]);
+                }
+                if constexpr (kRef) {
+                    // NaN products do not reach `hi` (fmax drops them) but do reach the sum
+                    const bool bad = mine && (!reassociation_is_exact(chunk_end - start, h, l) || sum != sum);
+                    if (__ballot(bad) != 0) {
+                        broken = true;
+                        resume = chunk_start;
+                    }
+                }
+                if (!broken) {
+                    total = sum;
+                    hi = h;
+                    lo = l;
+                }
             }
+            end = chunk_end;  // after the loop: the row's end
         }
-        // from here on `start, end` are the whole row: its length for the test, its entries for the ordered pass
-        end = __builtin_amdgcn_readfirstlane(reinterpret_cast<const uint32_t *>(smem[WAVES - 1] + kStripBytes + kBounds)[1]);
-        staged_whole = false;
+        if (broken) {
+            ordered = total;  // lanes 0..31: the exact sum of the entries before `resume`
+            start = resume;
+            staged_whole = false;
+            need_ordered = true;
+        }
+    } else if constexpr (kRef) {
+        // NaN products do not reach `hi` (fmax drops them) but do reach the sum
+        need_ordered = __ballot(mine && (!reassociation_is_exact(end - start, hi, lo) || total != total)) != 0;  // wave-uniform
     }
     if constexpr (kRef) {
-        // NaN products do not reach `hi` (fmax drops them) but do reach the sum
-        const bool redo = mine && (!reassociation_is_exact(end - start, hi, lo) || total != total);
-        if (__ballot(redo) != 0) {  // wave-uniform
+        if (need_ordered) {
 #ifdef MISPMM_TUNING
             if (lane == 0) atomicAdd(&mispmm_split_stats[0], 1ull);
 #endif
