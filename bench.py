@@ -197,7 +197,10 @@ class BsrBf16Workload(Workload):
         self.bsr = formats.csr_to_bsr(self.csr, block)
         self.b_host = synth.dense_b(self.csr.num_cols, n)
         self.a = ops.DeviceBSR.from_host(self.bsr)
-        self.bsrc = ops.DeviceBSRC.from_host(self.bsr)       # once-per-upload analysis: occupied columns per block row
+        # once-per-upload analysis: occupied columns per block row, (a) in 4 fixed step slots per block row for the
+        # workgroup-per-block-row kernel (default), (b) as a plain step list for the wave-per-block-row kernel (--kernel 2)
+        self.slots = ops.DeviceBSRCSlots.from_host(self.bsr)
+        self.bsrc = ops.DeviceBSRC.from_host(self.bsr)
         self.blocks16 = ops.f32_to_bf16(self.a.data)
         self.b16 = ops.f32_to_bf16(torch.from_numpy(self.b_host).cuda())
         self.c = torch.empty((self.csr.num_rows, n), dtype=torch.float32, device="cuda")
@@ -205,20 +208,33 @@ class BsrBf16Workload(Workload):
         self.b16_host = synth.bf16_round(self.b_host.reshape(-1)).reshape(self.b_host.shape)
         self.flops = datasets.spmm_flops(self.csr.nnz, n)                       # useful flops (non-zeros of A)
         self.executed_flops = 2.0 * self.bsr.num_blocks * block * block * n       # dense block products
-        self.abytes = datasets.bsr_algorithmic_bytes(self.bsr, n, elem=2, out_elem=4)
+        # algorithmic bytes = what the kernel that runs must move: ITS operand + B (bf16) + C (fp32).  The BSR-16 operand
+        # (dense 16 x 16 bf16 blocks) is what only the dense-block kernel reads; it is kept as a labelled second figure.
+        dense_b_c = self.csr.num_cols * n * 2 + self.csr.num_rows * n * 4
+        self.bsr16_bytes = datasets.bsr_algorithmic_bytes(self.bsr, n, elem=2, out_elem=4)
+        self.kernel_bytes = {"slots": self.slots.operand_bytes() + dense_b_c,
+                             "steps": self.bsrc.num_steps * (1024 + 128) + (self.bsr.num_block_rows + 1) * 4 + dense_b_c,
+                             "dense": self.bsr16_bytes}
+        self.which = {0: "slots", 1: "dense", 2: "steps"}.get(args.kernel, "slots")
+        self.abytes = self.kernel_bytes[self.which]
         self.workload = (f"{matrix} BSR block {block} {self.csr.num_rows}x{self.csr.num_cols} "
                          f"{self.bsr.num_blocks} blocks (nnz {self.csr.nnz}) x dense K={n} bf16, C fp32")
+        self.kernel_names = {"slots": "column-compacted block rows, workgroup per block row, 4 step slots (mispmm_bsrc_slots_bf16)",
+                             "steps": "column-compacted block rows, wave per block row (mispmm_bsrc_bf16)",
+                             "dense": "one B panel per block (mispmm_bsr_bf16)"}
         self.extra_config = {"block_dim": block, "blocks": int(self.bsr.num_blocks), "mfma_k_steps": int(self.bsrc.num_steps),
-                             "bsr_kernel": "column-compacted block rows (mispmm_bsrc_bf16)" if args.kernel != 1
-                             else "one B panel per block (mispmm_bsr_bf16)"}
+                             "bsr_kernel": self.kernel_names[self.which]}
         self.has_fast = False
 
-    def step(self, stream, acc=None, dense_blocks=None):
+    def step(self, stream, acc=None, which=None):
         from mispmm import ops
-        if (self.args.kernel == 1) if dense_blocks is None else dense_blocks:
+        which = which or self.which
+        if which == "dense":
             ops.spmm_bsr_bf16(self.a, self.blocks16, self.b16, out_bf16=False, out=self.c, stream=stream)
-        else:
+        elif which == "steps":
             ops.spmm_bsrc_bf16(self.bsrc, self.b16, out_bf16=False, out=self.c, stream=stream)
+        else:
+            ops.spmm_bsrc_slots_bf16(self.slots, self.b16, out_bf16=False, out=self.c, stream=stream)
 
     def host_result(self):
         return self.c.cpu().numpy()
@@ -455,16 +471,25 @@ def run_single(args):
                              "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src)},
     }
     if w.fmt == "bsr":
-        executed = w.executed_flops if args.kernel == 1 else 2.0 * w.bsrc.num_steps * 16 * 32 * w.n
+        executed = w.executed_flops if w.which == "dense" else 2.0 * w.bsrc.num_steps * 16 * 32 * w.n
         ex = executed / (launch_us * 1e-6) / 1e12
         out["mfma"] = {"executed_TFLOPs": round(ex, 2), "dense_bf16_peak_frac": round(ex / BF16_MFMA_PEAK_TFLOPS, 4),
                        "note": "MFMA flops actually executed (K steps x 16 x 32 x N x 2); `value` counts the useful flops (2*nnz*K)"}
+        out["roofline"]["bsr16_operand_bytes"] = w.bsr16_bytes
+        out["roofline"]["frac_vs_bsr16_operand"] = round(w.bsr16_bytes / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["roofline"]["bytes_note"] = ("algorithmic_bytes_per_launch = the operand of the kernel that ran (column lists + bf16 "
+                                         "tiles of the occupied columns) + B (bf16) + C (fp32); bsr16_operand_bytes = the same "
+                                         "with the dense 16 x 16 bf16 blocks of the BSR file as A (SURVEY 8(d) config 4)")
     if not args.no_extras and w.fmt == "bsr":
-        o = timer.measure(lambda: w.step(stream, dense_blocks=args.kernel != 1), min(args.steps, 500), rounds=3, precondition_s=0.01)
-        out["other_bsr_kernel"] = {"kernel_tag": capi.last_kernel(), "launch_us": round(o["median_us"], 4),
-                                   "roofline_frac": round(w.abytes / (o["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                   "note": "--kernel 1 = one B panel per 16x16 block (mispmm_bsr_bf16), default = column-compacted "
-                                           "block rows (mispmm_bsrc_bf16); both v_mfma_f32_16x16x32_bf16"}
+        out["other_bsr_kernels"] = {}
+        for other in ("slots", "steps", "dense"):
+            if other == w.which:
+                continue
+            o = timer.measure(lambda: w.step(stream, which=other), min(args.steps, 500), rounds=3, precondition_s=0.01)
+            out["other_bsr_kernels"][other] = {
+                "kernel": w.kernel_names[other], "kernel_tag": capi.last_kernel(), "launch_us": round(o["median_us"], 4),
+                "algorithmic_bytes_per_launch": w.kernel_bytes[other],
+                "roofline_frac": round(w.kernel_bytes[other] / (o["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         w.step(stream)
         torch.cuda.synchronize()
     if not args.no_extras:

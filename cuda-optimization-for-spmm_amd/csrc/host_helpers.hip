@@ -223,6 +223,43 @@ inline uint16_t bf16_rne(float x) {
 }
 }  // namespace
 
+namespace {
+// columns of block row R that hold a value which is still non-zero as bf16, as (block, column-in-block) codes
+// b * bC + j in the order the blocks store them (= ascending when block columns ascend): the k order of the MFMA steps
+int occupied_columns(uint32_t R, uint32_t bC, uint32_t numBlocks, const uint32_t *blockRowPtrs_host, const float *blocks_host,
+                     std::vector<uint64_t> &cols) {
+    cols.clear();
+    for (uint32_t b = blockRowPtrs_host[R]; b < blockRowPtrs_host[R + 1]; ++b) {
+        if (b >= numBlocks) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: block index %u out of range", b);
+        const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
+        for (uint32_t j = 0; j < bC; ++j) {
+            bool any = false;
+            for (uint32_t i = 0; i < 16 && !any; ++i) any = (bf16_rne(blk[static_cast<size_t>(i) * bC + j]) & 0x7FFFu) != 0;
+            if (any) cols.push_back(static_cast<uint64_t>(b) * bC + j);
+        }
+    }
+    return MISPMM_OK;
+}
+
+// step `s` of a block row's occupied-column list -> 32 B-row indices (0xFFFFFFFF = padding: a dropped read) and the
+// [16 rows][32 k] bf16 tile of the values gathered to those columns (zero under padding); s past the list = all padding
+void fill_step(const std::vector<uint64_t> &cols, uint32_t s, uint32_t bC, const uint32_t *blockColIdxs_host, const float *blocks_host,
+               uint32_t *cdst, uint16_t *tdst) {
+    for (uint32_t k = 0; k < 32; ++k) {
+        const size_t e = static_cast<size_t>(s) * 32 + k;
+        if (e < cols.size()) {
+            const uint32_t b = static_cast<uint32_t>(cols[e] / bC), j = static_cast<uint32_t>(cols[e] % bC);
+            cdst[k] = blockColIdxs_host[b] * bC + j;
+            const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
+            for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = bf16_rne(blk[static_cast<size_t>(i) * bC + j]);
+        } else {
+            cdst[k] = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = 0;
+        }
+    }
+}
+}  // namespace
+
 extern "C" int mispmm_bsr_compact_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
                                             const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,
                                             const float *blocks_host, uint32_t *nSteps_out, uint32_t *stepPtrs_out_host,
@@ -235,44 +272,54 @@ extern "C" int mispmm_bsr_compact_bf16_host(uint32_t numBlockRows, uint32_t bR, 
     if (!fill && (stepPtrs_out_host || cols_out_host || tiles_out_host))
         return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: give all three outputs or none (size query)");
     uint64_t steps = 0;
-    std::vector<uint32_t> cols;
+    std::vector<uint64_t> cols;
     for (uint32_t R = 0; R < numBlockRows; ++R) {
-        // columns of this block row that hold a value which is still non-zero as bf16, in the order the blocks store
-        // them (= ascending when block columns ascend): the k order of the MFMA steps
-        cols.clear();
-        for (uint32_t b = blockRowPtrs_host[R]; b < blockRowPtrs_host[R + 1]; ++b) {
-            if (b >= numBlocks) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact: block index %u out of range", b);
-            const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
-            for (uint32_t j = 0; j < bC; ++j) {
-                bool any = false;
-                for (uint32_t i = 0; i < 16 && !any; ++i) any = (bf16_rne(blk[static_cast<size_t>(i) * bC + j]) & 0x7FFFu) != 0;
-                if (any) cols.push_back(b * bC + j);  // (block, column-in-block) for now
-            }
-        }
+        if (int st = occupied_columns(R, bC, numBlocks, blockRowPtrs_host, blocks_host, cols)) return st;
         const uint32_t nsteps = static_cast<uint32_t>((cols.size() + 31) / 32);
         if (fill) {
             stepPtrs_out_host[R] = static_cast<uint32_t>(steps);
-            for (uint32_t s = 0; s < nsteps; ++s) {
-                uint32_t *cdst = cols_out_host + (steps + s) * 32;
-                uint16_t *tdst = tiles_out_host + (steps + s) * 512;
-                for (uint32_t k = 0; k < 32; ++k) {
-                    const size_t e = static_cast<size_t>(s) * 32 + k;
-                    if (e < cols.size()) {
-                        const uint32_t b = cols[e] / bC, j = cols[e] % bC;
-                        cdst[k] = blockColIdxs_host[b] * bC + j;
-                        const float *blk = blocks_host + static_cast<size_t>(b) * 16u * bC;
-                        for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = bf16_rne(blk[static_cast<size_t>(i) * bC + j]);
-                    } else {
-                        cdst[k] = 0xFFFFFFFFu;  // padding: a dropped B-row read, zero coefficients
-                        for (uint32_t i = 0; i < 16; ++i) tdst[i * 32 + k] = 0;
-                    }
-                }
-            }
+            for (uint32_t s = 0; s < nsteps; ++s)
+                fill_step(cols, s, bC, blockColIdxs_host, blocks_host, cols_out_host + (steps + s) * 32, tiles_out_host + (steps + s) * 512);
         }
         steps += nsteps;
     }
     if (steps > 0x03FFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "bsr compact: too many K steps");
     if (fill) stepPtrs_out_host[numBlockRows] = static_cast<uint32_t>(steps);
     *nSteps_out = static_cast<uint32_t>(steps);
+    return MISPMM_OK;
+}
+
+extern "C" int mispmm_bsr_compact_slots_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                                                  const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,
+                                                  const float *blocks_host, uint32_t *nSteps_out, uint32_t *nUsedSteps_out,
+                                                  uint32_t *extraPtrs_out_host, uint32_t *cols_out_host, uint16_t *tiles_out_host) {
+    constexpr uint32_t kSlots = 4;  // = kBsrSlots of bsr_slots.hpp
+    if (!nSteps_out) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact slots: nSteps_out is null");
+    if (bR != 16 || bC == 0) return fail(MISPMM_ERR_UNSUPPORTED, "bsr compact slots: block rows of 16 only (got %u x %u blocks)", bR, bC);
+    if (numBlockRows != 0 && !blockRowPtrs_host) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact slots: blockRowPtrs is null");
+    if (numBlocks != 0 && (!blockColIdxs_host || !blocks_host)) return fail(MISPMM_ERR_INVALID_ARG, "bsr compact slots: null block arrays");
+    const bool fill = extraPtrs_out_host && cols_out_host && tiles_out_host;
+    if (!fill && (extraPtrs_out_host || cols_out_host || tiles_out_host))
+        return fail(MISPMM_ERR_INVALID_ARG, "bsr compact slots: give all three outputs or none (size query)");
+    const uint64_t fixed = static_cast<uint64_t>(numBlockRows) * kSlots;
+    uint64_t extra = 0, used = 0;
+    std::vector<uint64_t> cols;
+    for (uint32_t R = 0; R < numBlockRows; ++R) {
+        if (int st = occupied_columns(R, bC, numBlocks, blockRowPtrs_host, blocks_host, cols)) return st;
+        const uint32_t nsteps = static_cast<uint32_t>((cols.size() + 31) / 32);
+        if (fill) {
+            extraPtrs_out_host[R] = static_cast<uint32_t>(extra);
+            for (uint32_t s = 0; s < std::max(nsteps, kSlots); ++s) {
+                const uint64_t at = s < kSlots ? static_cast<uint64_t>(R) * kSlots + s : fixed + extra + (s - kSlots);
+                fill_step(cols, s, bC, blockColIdxs_host, blocks_host, cols_out_host + at * 32, tiles_out_host + at * 512);
+            }
+        }
+        used += nsteps;
+        if (nsteps > kSlots) extra += nsteps - kSlots;
+    }
+    if (fixed + extra > 0x03FFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "bsr compact slots: too many K steps");
+    if (fill) extraPtrs_out_host[numBlockRows] = static_cast<uint32_t>(extra);
+    *nSteps_out = static_cast<uint32_t>(fixed + extra);
+    if (nUsedSteps_out) *nUsedSteps_out = static_cast<uint32_t>(used);
     return MISPMM_OK;
 }

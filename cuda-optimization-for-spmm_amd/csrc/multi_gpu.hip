@@ -6,12 +6,17 @@
 // runs the single-GPU kernel on its slice; the only exchange is the gather of the C row slabs:
 //   MISPMM_GATHER_TO_FIRST   every device copies its slab into device 0's C          (peer copies over xGMI)
 //   MISPMM_GATHER_ALL_PEER   every device copies its slab into every other device's C (all-gather by peer copies)
-//   MISPMM_GATHER_ALL_RCCL   grouped in-place ncclBroadcast of each slab from its owner (all-gather-v over RCCL)
+//   MISPMM_GATHER_ALL_RCCL   equal slabs: ONE in-place ncclAllGather per device; uneven slabs: grouped in-place
+//                            ncclBroadcast of each slab from its owner (all-gather-v)
+//   MISPMM_GATHER_ALL_RCCL_EQUAL  rows cut into equal chunks of ceil(M / ndev) (the last may be short, C padded to
+//                            ndev * chunk rows by the caller): always ONE in-place ncclAllGather per device
+// A C with ldc > N keeps its gap columns: peer copies move N columns per row (2-D copies), the RCCL modes refuse it.
 // Everything is enqueued on the caller's per-device streams; nothing here synchronises or allocates.
 // librccl.so is loaded on first use of mispmm_comm_create, so single-GPU users never pay for it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -39,6 +44,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -56,8 +62,9 @@ static Rccl &rccl() {
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast && r.GetErrorString;
+        r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast && r.AllGather && r.GetErrorString;
     });
     return r;
 }
@@ -160,7 +167,7 @@ int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_
     if (ndev == 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: no device");
     if (!devices || !streams || !rowBounds_host || !rowPtrs || !colIdxs || !vals || !nnz_host || !B || !C)
         return fail(MISPMM_ERR_INVALID_ARG, "multi: null argument array");
-    if (gather_mode < MISPMM_GATHER_NONE || gather_mode > MISPMM_GATHER_ALL_RCCL)
+    if (gather_mode < MISPMM_GATHER_NONE || gather_mode > MISPMM_GATHER_ALL_RCCL_EQUAL)
         return fail(MISPMM_ERR_INVALID_ARG, "multi: unknown gather mode %d", gather_mode);
     if (rowBounds_host[0] != 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: rowBounds[0] must be 0");
     for (uint32_t d = 0; d < ndev; ++d) {
@@ -168,10 +175,22 @@ int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_
         if (!B[d] || !C[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: B or C of device slot %u is null", d);
     }
     if (ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "multi: ldc smaller than N");
-    if (gather_mode == MISPMM_GATHER_ALL_RCCL) {
+    const bool rccl_mode = gather_mode == MISPMM_GATHER_ALL_RCCL || gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL;
+    // equal chunks: slab d starts at row d * chunk, only the last may be short (its gather then reads and writes up to
+    // ndev * chunk rows of C: the EQUAL mode's contract says the caller allocated them)
+    const uint32_t M = rowBounds_host[ndev], chunk = ceil_div(M, ndev);
+    bool equal_chunks = true;
+    for (uint32_t d = 0; d < ndev; ++d) equal_chunks = equal_chunks && rowBounds_host[d] == std::min(M, d * chunk);
+    const bool whole_chunks = equal_chunks && static_cast<uint64_t>(chunk) * ndev == M;
+    if (rccl_mode) {
         if (!comm || comm->comms.size() != ndev) return fail(MISPMM_ERR_INVALID_ARG, "multi: RCCL gather needs a communicator over the same %u devices", ndev);
         for (uint32_t d = 0; d < ndev; ++d)
             if (comm->devices[d] != devices[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: communicator device order differs");
+        // a collective moves whole contiguous runs: with ldc > N it would carry the gap columns of every row from the
+        // owner into everybody's C
+        if (ldc != N) return fail(MISPMM_ERR_UNSUPPORTED, "multi: the RCCL gathers need a dense C (ldc == N, got ldc=%u N=%u); use a peer gather", ldc, N);
+        if (gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL && !equal_chunks)
+            return fail(MISPMM_ERR_INVALID_ARG, "multi: GATHER_ALL_RCCL_EQUAL needs rowBounds[d] = d * ceil(M / ndev)");
     }
     DeviceGuard guard;
     // 1. every device multiplies its row range into its own rows of its C
@@ -195,21 +214,43 @@ int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_
         for (uint32_t d = 0; d < ndev; ++d) {
             const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
             if (rows == 0) continue;
-            const size_t off = static_cast<size_t>(r0) * ldc, bytes = (static_cast<size_t>(rows - 1) * ldc + N) * sizeof(float);
+            const size_t off = static_cast<size_t>(r0) * ldc;
             MISPMM_HIP_TRY(hipSetDevice(devices[d]));
             const uint32_t last = gather_mode == MISPMM_GATHER_TO_FIRST ? 1u : ndev;
             for (uint32_t e = 0; e < last; ++e) {
                 if (e == d || C[e] == C[d]) continue;
-                MISPMM_HIP_TRY(hipMemcpyPeerAsync(C[e] + off, devices[e], C[d] + off, devices[d], bytes, as_stream(streams[d])));
+                if (ldc == N) {  // dense C: the slab is one contiguous run
+                    MISPMM_HIP_TRY(hipMemcpyPeerAsync(C[e] + off, devices[e], C[d] + off, devices[d], static_cast<size_t>(rows) * N * sizeof(float),
+                                                      as_stream(streams[d])));
+                } else {  // strided C: N columns of every row, the gap columns of the destination stay as they are
+                    MISPMM_HIP_TRY(hipMemcpy2DAsync(C[e] + off, static_cast<size_t>(ldc) * sizeof(float), C[d] + off,
+                                                    static_cast<size_t>(ldc) * sizeof(float), static_cast<size_t>(N) * sizeof(float), rows,
+                                                    hipMemcpyDeviceToDevice, as_stream(streams[d])));
+                }
             }
         }
         return MISPMM_OK;
     }
+    if (equal_chunks && (whole_chunks || gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL)) {
+        // ONE in-place all-gather per device over equal slabs (device d's slab already sits at chunk d of its own C)
+        const size_t count = static_cast<size_t>(chunk) * N;
+        MISPMM_RCCL_TRY(rccl().GroupStart());
+        for (uint32_t d = 0; d < ndev; ++d) {
+            const ncclResult_t r = rccl().AllGather(C[d] + static_cast<size_t>(d) * count, C[d], count, ncclFloat, comm->comms[d], as_stream(streams[d]));
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return fail(MISPMM_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString(r));
+            }
+        }
+        MISPMM_RCCL_TRY(rccl().GroupEnd());
+        return MISPMM_OK;
+    }
+    // uneven slabs (nnz-balanced row ranges): all-gather-v as grouped in-place broadcasts, one per slab
     MISPMM_RCCL_TRY(rccl().GroupStart());
     for (uint32_t root = 0; root < ndev; ++root) {
         const uint32_t r0 = rowBounds_host[root], rows = rowBounds_host[root + 1] - r0;
         if (rows == 0) continue;
-        const size_t off = static_cast<size_t>(r0) * ldc, count = static_cast<size_t>(rows - 1) * ldc + N;
+        const size_t off = static_cast<size_t>(r0) * ldc, count = static_cast<size_t>(rows) * N;
         for (uint32_t d = 0; d < ndev; ++d) {
             const ncclResult_t r = rccl().Broadcast(C[d] + off, C[d] + off, count, ncclFloat, static_cast<int>(root), comm->comms[d],
                                                     as_stream(streams[d]));

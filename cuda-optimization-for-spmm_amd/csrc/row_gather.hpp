@@ -1,7 +1,7 @@
 // The row-group gather kernel shared by CSR (kernel 5), ELL and COO: G lanes own one C row, lane i
 // fetches entry i of the row's current G-entry chunk, B-row byte offsets are broadcast by lane
 // shuffle, up to 16 B-row reads per lane are in flight as dropped-or-live buffer loads, products
-// are summed in storage order, and C leaves through write-through stores.  Workgroups are laid
+// are summed in storage order, and C leaves through non-temporal buffer stores (spmm_common.hpp).  Workgroups are laid
 // over the 8 XCDs as a P x Q grid of (row part, column part) so each XCD's L2 holds 1/Q of the
 // width of the B rows that 1/P of the matrix rows touch (see k5 in spmm_csr.hip for the
 // traffic model).  `Rows` says where a row's entries live:
@@ -67,7 +67,7 @@ template <> struct BatchArg<true> {
     BatchPtrs p;
 };
 
-template <int G, int VEC, class Acc, bool SC1, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
+template <int G, int VEC, class Acc, bool CBUF, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
           bool BATCHED = false>
 __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
@@ -83,6 +83,11 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
 #ifdef MISPMM_STAMPS
     unsigned long long stamp[5];
     stamp[0] = wall_clock64();
+#endif
+#ifdef MISPMM_X_PRIO
+    // experiment (tools/r3_headline_variants.sh): a wave that has just started outranks its SIMD's older waves (which are
+    // busy with the sums of the gather phase) until its (col, val) reads are on their way
+    __builtin_amdgcn_s_setprio(3);
 #endif
     const float *__restrict__ B = B_one;
     float *__restrict__ C = C_one;
@@ -174,6 +179,9 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
             }
         };
         if (row_len != 0) fetch_super(0);
+#ifdef MISPMM_X_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef MISPMM_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp[1] = wall_clock64();
@@ -303,8 +311,8 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
         vec_t out;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
-        if constexpr (SC1) {
-            buffer_store_vec_sc1<VEC>(make_rsrc(C, c_bytes), (row * ldc + col0) * 4u, out);
+        if constexpr (CBUF) {  // buffer stores with the library's C store policy (non-temporal); else plain global stores
+            buffer_store_vec_c<VEC>(make_rsrc(C, c_bytes), (row * ldc + col0) * 4u, out);
         } else {
             store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
         }
@@ -348,7 +356,8 @@ struct RowGatherArgs {
     float *const *C_list = nullptr;
 };
 
-// P x Q XCD grid and the C store flavour.  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
+// P x Q XCD grid and the C store flavour (`sc1`, name kept from round 2: C through buffer stores with the policy of
+// spmm_common.hpp -- non-temporal -- instead of plain global stores).  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
 // the defaults (measurement aid; results never depend on them).
 struct XcdTiling {
     uint32_t log2p, q;
@@ -473,6 +482,12 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
             if (rows.width > 8 && rows.width <= 10) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 10>(a, rows, t);
             if (rows.width > 10 && rows.width <= 12) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 12>(a, rows, t);
             // (4 / 5 / 6 / 7 reads in flight instead of 8 on the headline: 3.85 / 3.74 / 3.72 / 3.67 us against 3.60-3.73)
+#ifdef MISPMM_TUNING
+            if constexpr (G == 16 && std::is_same_v<Rows, UniformRows>) {  // workgroup size of the headline's kernel (measurement aid)
+                if (rows.width > 12 && rows.width <= 14 && block == 64) return launch_row_gather_b<G, VEC, Acc, Rows, 64, 8, true, 14>(a, rows, t);
+                if (rows.width > 12 && rows.width <= 14 && block == 256) return launch_row_gather_b<G, VEC, Acc, Rows, 256, 8, true, 14>(a, rows, t);
+            }
+#endif
             if (rows.width > 12 && rows.width <= 14) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 14>(a, rows, t);
         }
     }

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "bsr_bf16_lds.hpp"
+#include "bsr_slots.hpp"
 #include "spmm_common.hpp"
 
 namespace mispmm {
@@ -889,3 +890,48 @@ extern "C" int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, u
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }
+
+extern "C" int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t nSteps, const uint32_t *extraPtrs,
+                                      const uint32_t *cols, const uint16_t *tiles, const uint16_t *B, uint32_t N, uint32_t ldb, void *C,
+                                      uint32_t ldc, int c_bf16) {
+    if (numBlockRows == 0 || N == 0) return MISPMM_OK;
+    if (!extraPtrs || !cols || !tiles || !B || !C) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: null pointer");
+    if (nSteps < static_cast<uint64_t>(numBlockRows) * kBsrSlots)
+        return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: nSteps %u is less than %u slots per block row", nSteps, kBsrSlots);
+    if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: leading dimension smaller than N");
+    if (N % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || !aligned16(B) || !aligned16(C) || !aligned16(tiles) || !aligned16(cols) ||
+        static_cast<uint64_t>(K) * ldb * 2u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsrc_slots_bf16: N / ldb / ldc must be multiples of 8, operands 16-byte aligned, B below 2 GiB");
+    const uint32_t nST = ceil_div(N, 128u);
+    const XcdGrid xg = xcd_grid(numBlockRows * nST);  // one workgroup per (block row, 128 columns)
+    const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 2u);
+    const uint64_t c_bytes = static_cast<uint64_t>(numBlockRows) * 16u * ldc * (c_bf16 ? 2u : 4u);
+    // C store policy: MISPMM_BSR_STORE = -1 plain global stores, 2 non-temporal, 16 write-through (sc1), 18 both
+    // (measurement aid; buffer stores need C below 2 GiB, else plain)
+    static const int store_knob = knob_int("MISPMM_BSR_STORE", 2);
+    const int st = c_bytes <= 0x7FFFFFFFull ? store_knob : -1;
+    note_kernel("bsrc_slots_mfma_bf16<%s,%s>", c_bf16 ? "c16" : "c32", st == 2 ? "nt" : st == 16 ? "sc1" : st == 18 ? "sc1nt" : "plain");
+#define MISPMM_SLOTS_LAUNCH(CB, ST)                                                                                            \
+    hipLaunchKernelGGL((bsrc_slots_mfma_bf16<CB, ST>), dim3(xg.grid), dim3(256), 0, as_stream(stream), numBlockRows, nST, extraPtrs, \
+                       cols, tiles, B, b_bytes, N, ldb, C, static_cast<uint32_t>(st >= 0 ? c_bytes : 0), ldc, xg.chunk)
+#define MISPMM_SLOTS_PICK(CB)                        \
+    do {                                             \
+        if (st == 2) MISPMM_SLOTS_LAUNCH(CB, 2);     \
+        else if (st == 16) MISPMM_SLOTS_LAUNCH(CB, 16); \
+        else if (st == 18) MISPMM_SLOTS_LAUNCH(CB, 18); \
+        else MISPMM_SLOTS_LAUNCH(CB, -1);            \
+    } while (0)
+    if (c_bf16) MISPMM_SLOTS_PICK(true); else MISPMM_SLOTS_PICK(false);
+#undef MISPMM_SLOTS_PICK
+#undef MISPMM_SLOTS_LAUNCH
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+#ifdef MISPMM_STAMPS
+// diagnostic build only: where the waves of bsrc_slots_mfma_bf16 leave their stamps (8 x uint64 per wave, 4 waves per workgroup)
+extern "C" int mispmm_debug_set_stamps_bsr(void *device_buffer) {
+    MISPMM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mispmm_bsr_stamp_buf), &device_buffer, sizeof(device_buffer)));
+    return MISPMM_OK;
+}
+#endif

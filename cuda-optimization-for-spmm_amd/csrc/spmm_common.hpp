@@ -76,20 +76,28 @@ __device__ __forceinline__ typename VecOf<VEC>::type buffer_load_vec(rsrc_t rsrc
 #define MISPMM_B_LOAD_AUX 0  // cache policy of the B-row reads of the row-gather kernel (measurement builds set 2 = nt)
 #endif
 
-// Write-through (sc1) vector store through a buffer descriptor: the bytes leave the XCD's L2 while
-// the kernel runs instead of being written back as dirty lines at the kernel boundary (measured on
-// a 3.2 MB C: 2.00 -> 1.63 us per back-to-back launch, tools/micro/launch_floor.hip).
+// C leaves through buffer stores with a cache policy (aux bits: 1 = sc0, 2 = nt, 16 = sc1).  Measured on the headline
+// (3.2 MB of C per launch, back-to-back launches; profiles/r3/store_policy.log): plain stores 3.66 us per launch (the
+// dirty lines are written back at the kernel boundary), sc1 write-through 3.60-3.66 (round 2's choice: every store waits
+// for the fabric), NON-TEMPORAL 3.39-3.41: nt lines are the L2's first candidates for eviction, so they stream out while
+// the kernel still runs and nobody waits for them.  Same ordering of the gains on ELL K=256 (6.18 -> 5.62 us) and on the
+// bf16 BSR kernel (sc1 6.9, plain 6.0, nt 5.1 us); sc1|nt together is the slowest form (11.2 us there).
+// Visibility is that of a plain store: the end-of-kernel release writes back whatever is still dirty.
+#ifdef MISPMM_X_STORE_AUX
+constexpr int kCStoreAux = MISPMM_X_STORE_AUX;  // experiment builds (make variant ... DEFS=-DMISPMM_X_STORE_AUX=16)
+#else
+constexpr int kCStoreAux = 2;  // nt
+#endif
 template <int VEC>
-__device__ __forceinline__ void buffer_store_vec_sc1(rsrc_t rsrc, uint32_t voffset, typename VecOf<VEC>::type v) {
-    constexpr int kSc1 = 16;  // cache-policy bit 4 on gfx940+
+__device__ __forceinline__ void buffer_store_vec_c(rsrc_t rsrc, uint32_t voffset, typename VecOf<VEC>::type v) {
     if constexpr (VEC == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, voffset, 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, voffset, 0, kCStoreAux);
     } else if constexpr (VEC == 2) {
         using u2 = uint32_t __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rsrc, voffset, 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rsrc, voffset, 0, kCStoreAux);
     } else {
         using u4 = uint32_t __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rsrc, voffset, 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rsrc, voffset, 0, kCStoreAux);
     }
 }
 

@@ -13,7 +13,7 @@
 //       pair to SGPRs, so the B row base is an SGPR pair and each B read a saddr-form global_load
 //   k4  k3 with two rows interleaved per wave (half the waves, twice the loads in flight)
 //   k5  (default) k1's row groups in 128-thread workgroups laid over the XCDs as a (row part x column
-//       part) grid, one 16-read batch per short row, write-through C stores: row_gather.hpp, shared
+//       part) grid, one 16-read batch per short row, non-temporal C stores: row_gather.hpp, shared
 //       with ELL and COO
 // Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void csr_k1(uint32_t M, const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------ k5
-// k1's row groups with a 2-D XCD tiling and write-through C stores: row_gather.hpp (shared with ELL
+// k1's row groups with a 2-D XCD tiling and non-temporal C stores: row_gather.hpp (shared with ELL
 // and COO).  The 8 XCDs form a P x Q grid (P * Q = 8): XCD x works on row part x % P and column
 // part x / P.  What leaves the L2s is  (sum over row parts of distinct B rows) * N*4 + Q * bytes(A):
 // fewer, larger row parts share more B rows, at the price of re-reading A once per column part and

@@ -6,7 +6,7 @@
 // fetches slot i of the row (one coalesced load per array, no row-pointer hop: the row's slots
 // sit at row * width), the B-row byte offsets are broadcast by lane shuffle and all `width` B
 // reads of a row go out back to back as bounds-checked buffer loads (padding slots are dropped
-// by the range check, not branched around), 2-D XCD tiling, write-through C stores.  Products are summed in slot order = ascending column order, the order in which the
+// by the range check, not branched around), 2-D XCD tiling, non-temporal C stores.  Products are summed in slot order = ascending column order, the order in which the
 // reference's spmmELLCpu reaches a given C row (spmm_ell.cpp:16-29), so REFERENCE mode is
 // bit-identical to it.  Roofline: HBM; algorithmic bytes = M*width*8 + K*N*4 + M*N*4.
 #include "row_gather.hpp"

@@ -4,6 +4,7 @@
 // (e.g. /root/reference/src/spmm/csr/spmm_csr_k3.cu:58-105): prolog = allocate C on every device, kernel =
 // per-device kernels + slab gather + sync of every stream, epilog = the gathered C copied back from device 0;
 // sharding A and replicating B are the multi-GPU equivalent of copy2Device and, like it, untimed.
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -49,6 +50,25 @@ bool spmmCSRMultiGpu(int ngpus, int gatherMode, SparseMatrixCSR<DT, MT> *a, Dens
         const uint32_t M = a->numRows, K = a->numCols, N = b->numCols;
         std::vector<uint32_t> bounds((size_t)ngpus + 1);
         mispmmCheckError(mispmm_shard_rows_by_nnz_host(M, a->rowPtrs, (uint32_t)ngpus, bounds.data()));
+        // RCCL gather: ONE ncclAllGather needs slabs of equal height.  Equal row chunks are taken instead of the
+        // nnz-balanced ranges when their heaviest slab carries at most 2 % more entries (always so for the uniform-row
+        // matrices of the BASELINE configs); C is then padded to ngpus * chunk rows.  Otherwise the uneven slabs travel
+        // as grouped broadcasts.
+        size_t cRows = M;
+        if (gatherMode == MISPMM_GATHER_ALL_RCCL && ngpus > 1) {
+            const uint32_t chunk = (M + (uint32_t)ngpus - 1) / (uint32_t)ngpus;
+            uint64_t heavyBalanced = 0, heavyEqual = 0;
+            for (int d = 0; d < ngpus; ++d) {
+                const uint32_t e0 = std::min<uint64_t>(M, (uint64_t)d * chunk), e1 = std::min<uint64_t>(M, (uint64_t)(d + 1) * chunk);
+                heavyBalanced = std::max<uint64_t>(heavyBalanced, a->rowPtrs[bounds[d + 1]] - a->rowPtrs[bounds[d]]);
+                heavyEqual = std::max<uint64_t>(heavyEqual, a->rowPtrs[e1] - a->rowPtrs[e0]);
+            }
+            if (heavyEqual * 100 <= heavyBalanced * 102) {
+                for (int d = 0; d <= ngpus; ++d) bounds[d] = (uint32_t)std::min<uint64_t>(M, (uint64_t)d * chunk);
+                gatherMode = MISPMM_GATHER_ALL_RCCL_EQUAL;
+                cRows = (size_t)chunk * ngpus;
+            }
+        }
 
         // untimed: device d gets its row slice (row pointers rebased), a replica of B
         std::vector<DeviceSlot> slots((size_t)ngpus);
@@ -74,12 +94,12 @@ bool spmmCSRMultiGpu(int ngpus, int gatherMode, SparseMatrixCSR<DT, MT> *a, Dens
         }
         if (ngpus > 1) mispmmCheckError(mispmm_enable_peer_access((uint32_t)ngpus, ordinals.data()));
         mispmm_comm_t comm = nullptr;
-        if (gatherMode == MISPMM_GATHER_ALL_RCCL) mispmmCheckError(mispmm_comm_create(&comm, (uint32_t)ngpus, ordinals.data()));
+        if (gatherMode == MISPMM_GATHER_ALL_RCCL || gatherMode == MISPMM_GATHER_ALL_RCCL_EQUAL) mispmmCheckError(mispmm_comm_create(&comm, (uint32_t)ngpus, ordinals.data()));
 
         const auto t1 = clock::now();
         for (DeviceSlot &s : slots) {  // prolog: C (zero-filled) on every device
             mispmmCheckError(mispmm_set_device(s.ordinal));
-            s.c = allocateBuffer<float>((size_t)M * N, true);
+            s.c = allocateBuffer<float>(cRows * N, true);
         }
         std::vector<mispmm_stream_t> streams;
         std::vector<const uint32_t *> rowPtrs, colIdxs;

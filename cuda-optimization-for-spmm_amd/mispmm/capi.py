@@ -15,7 +15,7 @@ ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3
 ACC_REFERENCE, ACC_FAST = 0, 1
 ACC_MODES = {"reference": ACC_REFERENCE, "fast": ACC_FAST}
 H2H, H2D, D2H, D2D = 0, 1, 2, 3
-GATHER_NONE, GATHER_TO_FIRST, GATHER_ALL_PEER, GATHER_ALL_RCCL = 0, 1, 2, 3
+GATHER_NONE, GATHER_TO_FIRST, GATHER_ALL_PEER, GATHER_ALL_RCCL, GATHER_ALL_RCCL_EQUAL = 0, 1, 2, 3, 4
 
 _c = ctypes
 _vp, _u32, _i, _sz = _c.c_void_p, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -67,6 +67,8 @@ SIGNATURES = {
     "mispmm_bsr_bf16": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_bsr_compact_bf16_host": (_i, [_u32, _u32, _u32, _u32, _vp, _vp, _vp, _c.POINTER(_u32), _vp, _vp, _vp]),
     "mispmm_bsrc_bf16": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
+    "mispmm_bsr_compact_slots_bf16_host": (_i, [_u32, _u32, _u32, _u32, _vp, _vp, _vp, _c.POINTER(_u32), _c.POINTER(_u32), _vp, _vp, _vp]),
+    "mispmm_bsrc_slots_bf16": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_coo_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _vp, _i, _i]),
     "mispmm_coo_row_bounds": (_i, [_vp, _u32, _u32, _vp, _vp]),
     "mispmm_coo_sort_by_row_host": (_i, [_u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i)]),

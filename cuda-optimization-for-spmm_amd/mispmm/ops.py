@@ -413,6 +413,52 @@ def spmm_bsrc_bf16(a, b_bf16, out_bf16=False, out=None, stream=None):
     return out
 
 
+@dataclass
+class DeviceBSRCSlots:
+    """Column-compacted block rows of a 16-row BSR in fixed step slots, one workgroup per block row
+    (mispmm_bsr_compact_slots_bf16_host)."""
+    num_rows: int
+    num_cols: int
+    num_steps: int           # extent of cols / tiles: 4 slots per block row + extra steps
+    used_steps: int          # steps that hold values (MFMA K steps executed)
+    extra_ptrs: torch.Tensor
+    cols: torch.Tensor
+    tiles: torch.Tensor      # int16 view of bf16 bits, [num_steps, 16, 32]
+
+    @staticmethod
+    def from_host(bsr, device="cuda"):
+        l = capi.lib()
+        ptrs = np.ascontiguousarray(bsr.block_row_ptrs, dtype=np.uint32)
+        cols = np.ascontiguousarray(bsr.block_col_idxs, dtype=np.uint32)
+        data = np.ascontiguousarray(bsr.data, dtype=np.float32).reshape(-1)
+        n, used = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        head = (bsr.num_block_rows, bsr.block_row_size, bsr.block_col_size, bsr.num_blocks, ptrs.ctypes.data, cols.ctypes.data,
+                data.ctypes.data, ctypes.byref(n), ctypes.byref(used))
+        capi.check(l.mispmm_bsr_compact_slots_bf16_host(*head, None, None, None))
+        ep = np.empty(bsr.num_block_rows + 1, dtype=np.uint32)
+        cl = np.empty(max(1, n.value) * 32, dtype=np.uint32)
+        tl = np.empty(max(1, n.value) * 512, dtype=np.uint16)
+        capi.check(l.mispmm_bsr_compact_slots_bf16_host(*head, ep.ctypes.data, cl.ctypes.data, tl.ctypes.data))
+        return DeviceBSRCSlots(bsr.num_rows, bsr.num_cols, n.value, used.value, _dev_u32(ep, device), _dev_u32(cl, device),
+                               torch.from_numpy(tl.view(np.int16).copy()).to(device))
+
+    def operand_bytes(self):
+        """Bytes of A one product must read: every slot's column list, the tiles of the used steps, the extra pointers."""
+        return self.num_steps * 128 + self.used_steps * 1024 + (self.num_rows // 16 + 1) * 4
+
+
+def spmm_bsrc_slots_bf16(a, b_bf16, out_bf16=False, out=None, stream=None):
+    """a: DeviceBSRCSlots, b_bf16: int16 tensor of bf16 bits [K, N]; fp32 (or bf16) C."""
+    _require_gpu(a.extra_ptrs, b_bf16)
+    n = b_bf16.shape[1]
+    if out is None:
+        out = torch.empty((a.num_rows, n), dtype=torch.int16 if out_bf16 else torch.float32, device=b_bf16.device)
+    capi.check(capi.lib().mispmm_bsrc_slots_bf16(_stream_ptr(stream), a.num_rows // 16, a.num_cols, a.num_steps, _p(a.extra_ptrs),
+                                                 _p(a.cols), _p(a.tiles), _p(b_bf16), n, b_bf16.stride(0), _p(out), out.stride(0),
+                                                 int(bool(out_bf16))))
+    return out
+
+
 def dense_transpose(x, stream=None):
     _require_gpu(x)
     x = x.contiguous()

@@ -277,6 +277,26 @@ int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, 
                      const uint32_t *cols, const uint16_t *tiles, const uint16_t *B, uint32_t N, uint32_t ldb, void *C, uint32_t ldc,
                      int c_bf16);
 
+/* The same compacted operand laid out for ONE WORKGROUP per (block row, 128 output columns): a block row's first 4 MFMA K
+ * steps sit in fixed slots -- step R * 4 + w belongs to wave w of block row R, slots past the row's step count hold a
+ * padding column list -- so no pointer is read in front of a column list and the steps of a block row run on 4 waves
+ * at once; steps past the fourth ("extra" steps, block rows with more than 128 occupied columns) follow the slots at
+ * index 4 * numBlockRows + extraPtrs[R] .. extraPtrs[R + 1].  The 4 partial tiles are added in wave order through LDS
+ * (fixed order: deterministic).  mispmm_bsrc_bf16 walks the same steps with one wave per block row: 3 dependent memory
+ * hops per step on 1250 waves (config 4: 6.2 us); this layout needs 2 hops and runs 5000 waves.
+ * HOST helper (once per upload): outputs NULL = size query; *nSteps_out = 4 * numBlockRows + extra steps (array
+ * extents: cols[nSteps * 32], tiles[nSteps * 512]), *nUsedSteps_out (may be NULL) = steps that hold values (what the
+ * kernel reads in full: an empty slot costs its 128-byte column list only); extraPtrs[numBlockRows + 1].
+ * Device call: operands as for mispmm_bsrc_bf16.  Replaces spmmBSRWrapper1 (src/spmm/bsr/spmm_bsr_k1.cu:44-91) for
+ * BASELINE.json config 4; bf16 is a new capability, the reference has none. */
+int mispmm_bsr_compact_slots_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
+                                       const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,
+                                       const float *blocks_host, uint32_t *nSteps_out, uint32_t *nUsedSteps_out,
+                                       uint32_t *extraPtrs_out_host, uint32_t *cols_out_host, uint16_t *tiles_out_host);
+int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, uint32_t nSteps, const uint32_t *extraPtrs,
+                           const uint32_t *cols, const uint16_t *tiles, const uint16_t *B, uint32_t N, uint32_t ldb, void *C,
+                           uint32_t ldc, int c_bf16);
+
 /* -------------------------------------------------------------- COO x dense */
 /* Row-major-sorted COO (the order convert_mtx.py:172-190 writes).  PRECONDITION: rowIdxs is
  * non-decreasing -- an unsorted array makes the row boundaries meaningless and the kernel read out of
@@ -352,8 +372,14 @@ enum mispmm_gather_mode {
     MISPMM_GATHER_NONE = 0,     /* C stays row-sharded */
     MISPMM_GATHER_TO_FIRST = 1, /* slabs copied into C[0] over xGMI (hipMemcpyPeerAsync on the owner's stream) */
     MISPMM_GATHER_ALL_PEER = 2, /* every slab copied into every other device's C */
-    MISPMM_GATHER_ALL_RCCL = 3  /* grouped in-place ncclBroadcast of each slab from its owner (all-gather-v) */
+    MISPMM_GATHER_ALL_RCCL = 3, /* slabs of equal height (rowBounds[d] = d * M / ndev): ONE in-place ncclAllGather per
+                                 * device; uneven slabs (nnz-balanced ranges): grouped in-place ncclBroadcast of each
+                                 * slab from its owner (all-gather-v) */
+    MISPMM_GATHER_ALL_RCCL_EQUAL = 4 /* rowBounds[d] = min(M, d * ceil(M / ndev)) REQUIRED, and every C[d] must hold
+                                 * ndev * ceil(M / ndev) rows (rows past M are scratch): always ONE ncclAllGather */
 };
+/* Strided C (ldc > N): the peer gathers copy N columns per row and leave the gap columns of every destination
+ * untouched; the RCCL gathers move contiguous runs and return MISPMM_ERR_UNSUPPORTED unless ldc == N. */
 int mispmm_enable_peer_access(uint32_t ndev, const int *devices);
 /* loads librccl.so on first use; MISPMM_ERR_UNSUPPORTED when it is not there */
 int mispmm_comm_create(mispmm_comm_t *comm, uint32_t ndev, const int *devices);

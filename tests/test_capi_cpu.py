@@ -152,6 +152,8 @@ def test_multi_entry_point_argument_errors():
     args = lambda gather, comm=None, b=bounds: (1, devs, one, b, 4, one, one, one, nnz, None, one, 8, 8, one, 8, 0, 0, gather, comm)  # noqa: E731
     assert l.mispmm_multi_csr_f32(*args(9)) == capi.ERR_INVALID_ARG
     assert l.mispmm_multi_csr_f32(*args(capi.GATHER_ALL_RCCL)) == capi.ERR_INVALID_ARG          # no communicator
+    assert l.mispmm_multi_csr_f32(*args(capi.GATHER_ALL_RCCL_EQUAL)) == capi.ERR_INVALID_ARG    # no communicator
+    assert l.mispmm_multi_csr_f32(*args(capi.GATHER_ALL_RCCL_EQUAL + 1)) == capi.ERR_INVALID_ARG
     assert l.mispmm_multi_csr_f32(*args(0, b=(ctypes.c_uint32 * 2)(1, 4))) == capi.ERR_INVALID_ARG   # bounds[0] != 0
     assert l.mispmm_multi_csr_f32(0, devs, one, bounds, 4, one, one, one, nnz, None, one, 8, 8, one, 8, 0, 0, 0, None) == capi.ERR_INVALID_ARG
     assert l.mispmm_slab_scatter(None, ctypes.c_void_p(16), 24, one, 1) == capi.ERR_INVALID_ARG  # not a 16-byte multiple
@@ -263,3 +265,51 @@ def test_rows_split_entry_validates_its_span_list():
     assert l.mispmm_rows_split_f32(*args(one, 4, acc=3)) == capi.ERR_INVALID_ARG
     assert l.mispmm_rows_split_f32(*args(one, 4, n=6, ld=6)) == capi.ERR_UNSUPPORTED          # 8-byte rows
     assert l.mispmm_rows_split_f32(None, 0, 4, 0, None, None, None, 0, None, 8, 8, None, 8, 0) == capi.OK
+
+
+def test_bsr_compact_slots_layout_matches_the_step_list():
+    """mispmm_bsr_compact_slots_bf16_host: the same occupied columns and tiles as mispmm_bsr_compact_bf16_host, the first 4
+    steps of block row R in slots 4R .. 4R+3 (unused slots all padding), the rest behind the slots through extraPtrs."""
+    rng = np.random.default_rng(5)
+    mb, kb, bc = 7, 30, 16
+    counts = [0, 1, 3, 9, 30, 2, 17]
+    ptrs, idxs, blocks = [0], [], []
+    for r in range(mb):
+        cols = np.sort(rng.choice(kb, size=counts[r], replace=False))
+        idxs += list(cols)
+        for _ in range(counts[r]):
+            blocks.append(np.where(rng.random((16, bc)) < 0.5, rng.uniform(-2, 2, (16, bc)), 0.0).astype(np.float32))
+        ptrs.append(len(idxs))
+    ptrs, idxs, data = np.array(ptrs, np.uint32), np.array(idxs, np.uint32), np.stack(blocks).reshape(-1)
+    l = capi.lib()
+    n_old = ctypes.c_uint32(0)
+    head = (mb, 16, bc, len(idxs), ptrs.ctypes.data, idxs.ctypes.data, data.ctypes.data)
+    capi.check(l.mispmm_bsr_compact_bf16_host(*head, ctypes.byref(n_old), None, None, None))
+    sp, cl, tl = np.empty(mb + 1, np.uint32), np.empty(n_old.value * 32, np.uint32), np.empty(n_old.value * 512, np.uint16)
+    capi.check(l.mispmm_bsr_compact_bf16_host(*head, ctypes.byref(n_old), sp.ctypes.data, cl.ctypes.data, tl.ctypes.data))
+    n_new, used = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    capi.check(l.mispmm_bsr_compact_slots_bf16_host(*head, ctypes.byref(n_new), ctypes.byref(used), None, None, None))
+    assert used.value == n_old.value
+    ep, cs, ts = np.empty(mb + 1, np.uint32), np.empty(n_new.value * 32, np.uint32), np.empty(n_new.value * 512, np.uint16)
+    capi.check(l.mispmm_bsr_compact_slots_bf16_host(*head, ctypes.byref(n_new), None, ep.ctypes.data, cs.ctypes.data, ts.ctypes.data))
+    cl, tl, cs, ts = cl.reshape(-1, 32), tl.reshape(-1, 512), cs.reshape(-1, 32), ts.reshape(-1, 512)
+    assert n_new.value == 4 * mb + int(ep[-1]) and ep[0] == 0
+    for r in range(mb):
+        steps = int(sp[r + 1] - sp[r])
+        assert int(ep[r + 1] - ep[r]) == max(0, steps - 4)
+        for q in range(4):
+            if q < steps:
+                assert np.array_equal(cs[4 * r + q], cl[sp[r] + q]) and np.array_equal(ts[4 * r + q], tl[sp[r] + q])
+            else:
+                assert np.all(cs[4 * r + q] == 0xFFFFFFFF) and np.all(ts[4 * r + q] == 0)
+        for e in range(max(0, steps - 4)):
+            at = 4 * mb + int(ep[r]) + e
+            assert np.array_equal(cs[at], cl[sp[r] + 4 + e]) and np.array_equal(ts[at], tl[sp[r] + 4 + e])
+    assert max(int(sp[r + 1] - sp[r]) for r in range(mb)) > 4            # the case really has extra steps
+    # argument errors: block rows of 16 only, all outputs or none
+    assert l.mispmm_bsr_compact_slots_bf16_host(mb, 8, bc, len(idxs), ptrs.ctypes.data, idxs.ctypes.data, data.ctypes.data,
+                                                ctypes.byref(n_new), None, None, None, None) == capi.ERR_UNSUPPORTED
+    assert l.mispmm_bsr_compact_slots_bf16_host(*head, ctypes.byref(n_new), None, ep.ctypes.data, None, None) == capi.ERR_INVALID_ARG
+    one = ctypes.c_void_p(16)
+    assert l.mispmm_bsrc_slots_bf16(None, 4, 64, 15, one, one, one, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG   # fewer than 4 slots per row
+    assert l.mispmm_bsrc_slots_bf16(None, 4, 64, 16, one, one, one, one, 12, 16, one, 16, 0) == capi.ERR_UNSUPPORTED  # N % 8

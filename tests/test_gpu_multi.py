@@ -47,6 +47,56 @@ def test_single_process_multi_device_entry_point(oracle, name, n):
             job.close()
 
 
+def test_gather_keeps_the_gap_columns_of_a_strided_c(oracle):
+    """ldc > N: the peer gathers copy N columns per row (the gap columns of every destination keep their sentinel);
+    the RCCL gathers move contiguous runs and refuse a strided C."""
+    from mispmm.multi import MultiCsrSpmm
+    csr = datasets.load_csr("qh1484")
+    n, ld = 40, 48
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for devices, gather in (([0, 0], "first"), ([0, 0, 0], "peer"), ([0], "peer")):
+        job = MultiCsrSpmm(csr, n, devices, gather=gather, ldc=ld)
+        for c in job.c:
+            c.fill_(-7.0)
+        job.set_b(b)
+        job.step()
+        job.sync()
+        for slot in range(len(devices) if gather == "peer" else 1):
+            whole = job.c[slot].cpu().numpy()
+            assert np.array_equal(whole[:, :n], ref), (devices, gather, slot)
+            assert np.all(whole[:, n:] == -7.0), (devices, gather, slot)
+        job.close()
+    job = MultiCsrSpmm(csr, n, [0], gather="rccl", ldc=ld)
+    job.set_b(b)
+    with pytest.raises(capi.MispmmError) as e:
+        job.step()
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    job.close()
+
+
+def test_rccl_gather_takes_one_allgather_over_equal_slabs(oracle):
+    """GATHER_ALL_RCCL_EQUAL: equal row chunks, C padded to ndev * chunk rows, ONE in-place ncclAllGather per device
+    (a communicator of one rank here: RCCL refuses the same device twice; the 8-GPU run is the driver's)."""
+    from mispmm.multi import MultiCsrSpmm
+    csr = datasets.load_csr("n4c6-b13")
+    n = 128
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for gather in ("rccl-equal", "rccl"):
+        job = MultiCsrSpmm(csr, n, [0], gather=gather)
+        job.set_b(b)
+        for _ in range(2):
+            job.step()
+        job.sync()
+        assert np.array_equal(job.full_c(0).cpu().numpy(), ref), gather
+        job.close()
+    # the bounds the mode requires: chunks of ceil(M / ndev) rows, checked by the entry point
+    job = MultiCsrSpmm(csr, n, [0, 0, 0], gather="none")
+    assert [int(x) for x in MultiCsrSpmm(csr, n, [0], gather="rccl-equal").bounds] == [0, csr.num_rows]
+    job.close()
+
+
 def test_slab_scatter_copies_to_every_destination():
     import ctypes
     src = torch.arange(4096 * 3 + 4, dtype=torch.float32, device="cuda")

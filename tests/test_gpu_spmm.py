@@ -767,6 +767,73 @@ def test_bsrc_bf16_small_and_ragged_block_rows(oracle):
         ops.spmm_bsrc_bf16(ops.DeviceBSRC.from_host(bsr), ops.f32_to_bf16(dev(synth.dense_b(kb * bc, 12))))
 
 
+@pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (256, True), (8, False)])
+def test_bsrc_slots_bf16_workgroup_per_block_row(oracle, n, out_bf16):
+    """mispmm_bsrc_slots_bf16 (BASELINE config 4's default kernel from round 3): the compacted steps of a block row in 4
+    fixed slots, one wave each, partial tiles added in wave order through LDS.  Same oracle and bound as the other bf16
+    kernels; the layout keeps exactly the occupied columns mispmm_bsrc_bf16 keeps."""
+    csr = datasets.load_csr("ACTIVSg10K")
+    bsr = formats.csr_to_bsr(csr, 16)
+    a = ops.DeviceBSRCSlots.from_host(bsr)
+    old = ops.DeviceBSRC.from_host(bsr)
+    assert a.used_steps == old.num_steps and a.num_steps >= 4 * bsr.num_block_rows
+    acols = a.cols.cpu().numpy().view(np.uint32)
+    assert int((acols != 0xFFFFFFFF).sum()) == int((old.cols.cpu().numpy().view(np.uint32) != 0xFFFFFFFF).sum())
+    b = synth.dense_b(csr.num_cols, n)
+    a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    c = ops.spmm_bsrc_slots_bf16(a, ops.f32_to_bf16(dev(b)), out_bf16=out_bf16)
+    assert "bsrc_slots" in capi.last_kernel()
+    got = (ops.bf16_to_f32(c) if out_bf16 else c).cpu().numpy()
+    scale = abs_scale(formats.CSR(csr.num_rows, csr.num_cols, csr.row_ptrs, csr.col_idxs, synth.bf16_round(csr.data)), b16)
+    if out_bf16:
+        assert np.all(np.abs(got - ref) <= 2 ** -8 * np.abs(ref) + 2e-6 * scale + 1e-30)
+    else:
+        assert np.all(np.abs(got.astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+    again = ops.spmm_bsrc_slots_bf16(a, ops.f32_to_bf16(dev(b)), out_bf16=out_bf16)
+    assert torch.equal(c, again)                                     # deterministic
+
+
+def test_bsrc_slots_bf16_ragged_rows_extra_steps_and_strides(oracle):
+    """Block rows with 0 .. 11 steps (more than 4 = extra steps behind the slots), 16 x 8 blocks, C and B with a
+    leading dimension larger than N (the gap in C keeps its sentinel), a width that is refused."""
+    rng = np.random.default_rng(12)
+    mb, kb, bc = 10, 60, 8
+    ptrs, idxs, blocks = [0], [], []
+    for r in range(mb):
+        cnt = [0, 1, 12, 3, 0, 7, 25, 2, 44, 60][r]
+        cols = np.sort(rng.choice(kb, size=cnt, replace=False))
+        idxs += list(cols)
+        for _ in range(cnt):
+            blocks.append(np.where(rng.random((16, bc)) < 0.6, rng.uniform(-2, 2, (16, bc)), 0.0).astype(np.float32))
+        ptrs.append(len(idxs))
+    data = np.stack(blocks)
+    bsr = formats.BSR(mb * 16, kb * bc, int(data.size), 16, bc, np.array(ptrs, np.uint32), np.array(idxs, np.uint32), data)
+    a = ops.DeviceBSRCSlots.from_host(bsr)
+    extra = a.extra_ptrs.cpu().numpy().view(np.uint32)
+    assert extra[-1] > 0 and a.num_steps == 4 * mb + int(extra[-1])  # the wide block rows really spill into extra steps
+    n, ld = 136, 144
+    b = synth.dense_b(kb * bc, n)
+    a16 = synth.bf16_round(data.reshape(-1)).reshape(data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    ref = oracle.spmm_bsr(mb * 16, 16, bc, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    scale = np.abs(bsr_to_dense(bsr, a16)).astype(np.float64) @ np.abs(b16).astype(np.float64)
+    bw = torch.zeros((kb * bc, ld), dtype=torch.int16, device="cuda")
+    bw[:, :n] = ops.f32_to_bf16(dev(b))
+    for sc1 in (True,):
+        cw = torch.full((mb * 16, ld), -7.0, device="cuda")
+        ops.spmm_bsrc_slots_bf16(a, bw[:, :n], out=cw[:, :n])
+        got = cw.cpu().numpy()
+        assert np.all(np.abs(got[:, :n].astype(np.float64) - ref) <= 2e-6 * scale + 1e-30)
+        assert np.all(got[:, n:] == -7.0)
+        assert np.all(got[4 * 16:5 * 16, :n] == 0)                   # an empty block row is overwritten with zeros
+    dense = ops.spmm_bsrc_bf16(ops.DeviceBSRC.from_host(bsr), ops.f32_to_bf16(dev(b))).cpu().numpy()
+    assert np.all(np.abs(dense.astype(np.float64) - got[:, :n]) <= 4e-6 * scale + 1e-30)
+    with pytest.raises(capi.MispmmError):
+        ops.spmm_bsrc_slots_bf16(a, ops.f32_to_bf16(dev(synth.dense_b(kb * bc, 12))))
+
+
 def bsr_to_dense(bsr, data):
     d = np.zeros((bsr.num_rows, bsr.num_cols), dtype=np.float32)
     br, bc = bsr.block_row_size, bsr.block_col_size
