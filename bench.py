@@ -51,7 +51,7 @@ PRECONDITION_S = 0.05            # untimed replays before the timed region
 TIMED_S = 0.02                   # minimum length of one timed round
 ROUNDS = 5
 MIN_GRAPH_NODES = 1000           # launches per captured graph (the K steps are captured ceil(1000 / K) times over)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2", "traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3", "traffic.json")
 _REAL_STDOUT = None
 
 
@@ -77,9 +77,9 @@ def parse():
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
     p.add_argument("--bucket", type=int, default=0, help="N>1: steps per C-slab exchange and per bucket hipGraph (0 = 64)")
-    p.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "both"],
-                   help="N>1: how C slabs travel (default: RCCL all-gather); `peer` = direct stores into IPC-mapped peer "
-                        "buffers, `both` measures the two and reports the faster as `value`")
+    p.add_argument("--exchange", default="both", choices=["allgather", "peer", "both"],
+                   help="N>1: how C slabs travel: `allgather` = RCCL all_gather_into_tensor, `peer` = direct stores into "
+                        "IPC-mapped peer buffers, `both` (default) measures the two and reports the faster as `value`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the other accumulate mode and the cold single shot (profiling passes use this)")
@@ -445,7 +445,8 @@ def run_single(args):
 
     launch_us = stat["median_us"]
     achieved = w.abytes / (launch_us * 1e-6) / 1e9
-    traffic, traffic_src = load_traffic(f"{args.config}:{w.matrix}/{w.n}/{args.acc}", kernel_tag)
+    traffic, traffic_src = load_traffic(f"{args.config}:{w.matrix}/{w.n}/{args.acc}" + ("/nohint" if os.environ.get("MISPMM_NO_HINT") == "1" else ""),
+                                        kernel_tag)
     info = capi.device_info(0)
     out = {
         "metric": metric_label(w),
@@ -588,10 +589,12 @@ def run_multi(args):
     b_host = synth.dense_b(csr.num_cols, n) if rank == 0 else None
     flops = datasets.spmm_flops(csr.nnz, n)
     abytes = datasets.csr_algorithmic_bytes(csr, n)
-    results, whole = {}, None
+    results, whole, gathered_host = {}, None, None
+    shard_bounds = mdist.shard_bounds(csr.row_ptrs, world)
     for mode in modes:
         try:
-            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode)
+            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode,
+                                       debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
         except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
             results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
             job = None
@@ -639,11 +642,27 @@ def run_multi(args):
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok[0]) == 0.0:
             raise SystemExit(f"bench: exchanged C ({mode}) differs from the unsharded product -- refusing to report a number")
+        if rank == 0:
+            gathered_host = job.gathered_c().cpu().numpy()
         results[mode] = {"replays": replays,
                          "value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
                          "kernel_only_value": round(flops * args.steps / compute_s / 1e9, 2),
                          "kernel_only_ms_per_step": round(compute_s * 1e3 / args.steps, 6)}
+        if job.debug_sentinel:
+            # MISPMM_DIST_DEBUG=1: every wait for a bucket checked that all peers' sentinels (written behind their slabs)
+            # had already arrived -- the timing of such a run is not a measurement (host syncs per bucket)
+            results[mode]["sentinel_checks"] = job.sentinel_checks
         job.close()
+    # who took part: every rank reports its device (PCI bus id) and the algorithmic bytes of ITS shard -- its slice of A,
+    # the B rows its columns touch, its C slab ("multi-GPU per device ... node total = sum")
+    r0, r1 = int(shard_bounds[rank]), int(shard_bounds[rank + 1])
+    e0, e1 = int(csr.row_ptrs[r0]), int(csr.row_ptrs[r1])
+    touched = int(np.unique(csr.col_idxs[e0:e1]).size)
+    mine = {"rank": rank, "device": dev_index, "bus_id": capi.device_bus_id(dev_index), "host": os.uname().nodename,
+            "rows": r1 - r0, "nnz": e1 - e0, "b_rows_touched": touched,
+            "algorithmic_bytes": (e1 - e0) * 8 + (r1 - r0 + 1) * 4 + touched * n * 4 + (r1 - r0) * n * 4}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
     if rank == 0:
         usable = {m: r for m, r in results.items() if "value" in r}
         if not usable:
@@ -651,6 +670,9 @@ def run_multi(args):
         best = max(usable, key=lambda m: usable[m]["value"])
         r = usable[best]
         label = "large_25605" if cfg_matrix == "n4c6-b13" else cfg_matrix
+        node_bytes = int(sum(e["algorithmic_bytes"] for e in everyone))
+        devices_seen = sorted({(e["host"], e["bus_id"]) for e in everyone})
+        ko_s, e2e_s = r["kernel_only_ms_per_step"] * 1e-3, r["ms_per_step"] * 1e-3
         out = {
             "metric": f"SpMM GFLOP/s, {label} ({cfg_matrix}) CSR x dense K={n} fp32",
             "value": r["value"], "unit": "GFLOP/s", "n_gpus": world,
@@ -663,15 +685,30 @@ def run_multi(args):
                                                       "direct copies into IPC-mapped peer buffers over xGMI") + ")",
                        "kernel": args.kernel, "acc_mode": args.acc,
                        "check": "exchanged C == unsharded single-GPU C (bitwise) on every rank"},
-            "achieved_hbm_GBps": round(abytes / (r["ms_per_step"] * 1e-3) / 1e9, 1),
+            "ranks_seen": {"world_size": world, "distinct_devices": len(devices_seen),
+                           "devices": [f"{h}/{b}" for h, b in devices_seen],
+                           "backend": "gloo (ranks share one card: MISPMM_SHARE_GPU rehearsal)" if shared_gpu else "nccl (RCCL)",
+                           "per_rank": everyone},
+            "achieved_hbm_GBps": round(abytes / e2e_s / 1e9, 1),
             "exchange_modes": results,
             "kernel_only": {"value": r["kernel_only_value"], "unit": "GFLOP/s", "ms_per_step": r["kernel_only_ms_per_step"],
                             "note": "the same steps re-run with C left row-sharded (no exchange), max over ranks"},
-            "roofline": {"bound": "hbm", "achieved": round(abytes / (r["kernel_only_ms_per_step"] * 1e-3) / 1e9, 1),
+            "roofline": {"bound": "hbm", "achieved": round(node_bytes / ko_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                         "frac": round(abytes / (r["kernel_only_ms_per_step"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
-                         "traffic": None, "note": "kernel-only time against the N-GPU aggregate HBM peak"},
+                         "frac": round(node_bytes / ko_s / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "frac_end_to_end": round(node_bytes / e2e_s / 1e9 / (HBM_PEAK_GBS * world), 4),
+                         "traffic": None, "algorithmic_bytes_per_launch": node_bytes,
+                         "single_gpu_algorithmic_bytes": abytes,
+                         "note": "algorithmic bytes = sum over ranks of (A slice + B rows its columns touch + C slab); "
+                                 "frac = those bytes / kernel-only time (C left row-sharded) against the N-GPU aggregate "
+                                 "HBM peak, frac_end_to_end = the same bytes / ms_per_step (exchange included)"},
         }
+        if not args.no_cpu_baseline:
+            # the same CPU leg as at N = 1: the oracle, 1 thread, rank 0's host, and the checker of the exchanged C
+            shim = CsrWorkload.__new__(CsrWorkload)
+            shim.csr, shim.b_host, shim.flops, shim.n = csr, b_host, flops, n
+            shim.workload = out["config"]["workload"]
+            out["cpu_baseline"] = cpu_baseline(shim, args.cpu_seconds, gathered_host, args.acc)
         emit(out)
     dist.barrier()
     dist.destroy_process_group()
@@ -679,23 +716,63 @@ def run_multi(args):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` started plainly: start one child per rank (fresh processes; this parent never
-    touches the GPU), relay rank 0's JSON line, exit with the worst child status."""
+    touches the GPU), relay rank 0's JSON line, exit non-zero if any rank failed.  Every child is watched: when one
+    dies the others are terminated (a rank that lost a peer would sit in a collective until the RCCL watchdog fires);
+    if the rendezvous port was taken (bind-then-close can collide), a fresh set of children is started on a new port."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MISPMM_BENCH_CHILD="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, out)
-    sys.exit(rc)
+    import tempfile
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    for attempt in range(3):
+        port = free_port()
+        procs, errs = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MISPMM_BENCH_CHILD="1")
+            err = tempfile.TemporaryFile()
+            errs.append(err)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=err))
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for i, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = i
+                    break
+            time.sleep(0.05)
+        if failed is None:
+            failed = next((i for i, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            for p in procs:                       # exactly the children started above, nothing else
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        out = procs[0].stdout.read() if procs[0].stdout else b""
+        texts = []
+        for err in errs:
+            err.seek(0)
+            texts.append(err.read().decode(errors="replace"))
+            err.close()
+        if failed is None:
+            sys.stderr.write(texts[0])
+            os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, out)
+            sys.exit(0)
+        collided = any("EADDRINUSE" in t or "address already in use" in t.lower() for t in texts)
+        sys.stderr.write(f"bench: rank {failed} exited with {procs[failed].returncode}; the other ranks were stopped\n")
+        sys.stderr.write(texts[failed][-4000:])
+        if not (collided and attempt < 2):
+            sys.exit(procs[failed].returncode or 1)
+        sys.stderr.write("bench: the rendezvous port was taken -- starting fresh ranks on another port\n")
+    sys.exit(1)
 
 
 def main():

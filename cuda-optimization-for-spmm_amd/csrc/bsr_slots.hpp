@@ -5,13 +5,13 @@
 // (stepPtrs -> column list -> B rows) once per step: ACTIVSg10K has 1250 block rows of 2-4 steps, so 1250 waves on
 // 1024 SIMDs each wait out ~3 + 2.7 round trips -- latency-bound at 6.2 us for 19 MB.  Here
 //   * a block row's first kSlots = 4 steps sit in FIXED slots (step R * 4 + w belongs to wave w of block row R): no
-//     pointer hop in front of the column list; slots past the row's step count hold a padding column list (128 bytes
-//     read, nothing else);  steps past the fourth are "extra" steps found through extraPtrs (scalar load, issued with
+//     pointer hop in front of the column list, which -- the step being wave-uniform -- is read through the scalar
+//     cache; slots past the row's step count hold a padding column list (128 bytes read, nothing else);  steps past the fourth are "extra" steps found through extraPtrs (scalar load, issued with
 //     the first hop);
 //   * every wave therefore runs hop 1 (its slot's 32 column indices) -> hop 2 (its 32 B rows x 256 bytes and its A
 //     tile) -> 8 MFMAs, all 4 waves of a block row at the same time;
-//   * the 4 partial 16 x 128 tiles are added in wave order (= ascending step order for rows of <= 4 steps) through
-//     LDS, each wave finishing and storing 4 of the 16 rows as whole 512-byte (fp32 C) / 256-byte (bf16 C) segments.
+//   * the 4 partial 16 x 128 tiles are added in wave order (= ascending step order for rows of <= 4 steps): waves 1..3
+//     park theirs in LDS, wave 0 adds them to its own and stores the 16 rows.
 // Deterministic; same operand rounding and the same bound against the oracle as bsrc_mfma_bf16, sums in a different
 // (fixed) order.  Replaces the thread-per-block-element atomicAdd kernel of /root/reference/src/spmm/bsr/spmm_bsr_k1.cu:9-41
 // for BASELINE config 4 (bf16 is a new capability: the reference has none).
@@ -31,8 +31,17 @@ static __device__ unsigned long long *mispmm_bsr_stamp_buf = nullptr;
 #endif
 
 // ST: cache policy of the C stores -- -1 = plain global stores, else buffer stores with that aux value (2 = nt, 16 = sc1)
+//
+// Resources decide whether this kernel works at all: config 4 has 1250 block rows for 256 CUs (4.9 workgroups per CU
+// on average, but the dispatcher hands some shader engines 6 per CU), and a workgroup that has to wait for a slot
+// starts ~3 us late (stamps: profiles/r3/stamps_bsrc_slots.log).  So the footprint is kept to 6+ workgroups per CU:
+//   * every step is multiplied into FRESH accumulators (the first MFMA of a tile takes the constant 0 as its addend), so
+//     no accumulator is live while the 8 B-row reads (32 VGPRs) are in flight;
+//   * waves 1..3 park their tile in LDS (24 KiB per workgroup), wave 0 keeps its own in registers and adds the three
+//     parked tiles in wave order; extra steps (block rows of more than 4 steps) go to waves 1..3 only, which add them
+//     into their parked tile -- a lane re-reads exactly the words it wrote, so that needs no barrier.
 template <bool C_BF16, int ST>
-__global__ __launch_bounds__(256) void bsrc_slots_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ extraPtrs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void bsrc_slots_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ extraPtrs,
                                                             const uint32_t *__restrict__ cols, const uint16_t *__restrict__ tiles,
                                                             const uint16_t *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
                                                             void *__restrict__ Cv, uint32_t c_bytes, uint32_t ldc, uint32_t xcd_chunk) {
@@ -44,11 +53,9 @@ __global__ __launch_bounds__(256) void bsrc_slots_mfma_bf16(uint32_t Mb, uint32_
     using bf16x8_t = short __attribute__((ext_vector_type(8)));
     using u32x4_t = uint32_t __attribute__((ext_vector_type(4)));
     constexpr int TPL = 8;
-    // [wave][row of the block row][128 columns]: 32 KiB, so that 5 workgroups fit a CU's 160 KiB and all 1250 block rows of
-    // config 4 are resident at once (4.9 per CU).  No padding needed: a ds_write_b128 is served in groups of 8 consecutive
-    // lanes = 256 contiguous bytes, a ds_read_b128 row segment is 512 contiguous bytes.
-    constexpr int LDP = 128;
-    __shared__ float partial[kBsrSlots][16][LDP];
+    // [wave - 1][row of the block row][128 columns]: 24 KiB.  No padding needed: a ds_write_b128 is served in groups of
+    // 8 consecutive lanes = 256 contiguous bytes here, and so is the read back.
+    __shared__ float parked[kBsrSlots - 1][16][128];
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -61,118 +68,155 @@ __global__ __launch_bounds__(256) void bsrc_slots_mfma_bf16(uint32_t Mb, uint32_
     const uint32_t lane_off = ncol < N ? ncol * 2u : kDropLoad;
     const uint32_t ldb2 = ldb * 2u;
 
-    f32x4_t acc[TPL];
+    // this lane's 8 B-row indices of step s (lane group g multiplies k = 8g .. 8g+7).  The step index is wave-uniform, so
+    // the 32 indices come through the SCALAR cache (two s_load_dwordx16) and are dealt to the lane groups by selects:
+    // a vector load here queues behind the B reads of the waves that started earlier (stamps: 0.6 us median, 1.4 us p90
+    // for 128 bytes) and every B read of this wave waits for it
+    struct Idx {
+        uint32_t v[8];
+    };
+    auto load_idx = [&](uint32_t s, Idx &ix) {
+        using u32x16_t = uint32_t __attribute__((ext_vector_type(16)));
+        const u32x16_t *p = reinterpret_cast<const u32x16_t *>(cols + static_cast<size_t>(__builtin_amdgcn_readfirstlane(s)) * 32u);
+        const u32x16_t lo = p[0], hi = p[1];  // whole-vector loads: hipcc otherwise turns the selects into branches around single loads
+        // branch-free deal (v_and_or_b32 with the index in an SGPR): ternaries here become 32 exec-masked branches
+        const uint32_t m0 = g == 0 ? ~0u : 0u, m1 = g == 1 ? ~0u : 0u, m2 = g == 2 ? ~0u : 0u, m3 = g == 3 ? ~0u : 0u;
 #pragma unroll
-    for (int t = 0; t < TPL; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    struct Step {
-        u32x4_t araw;
+        for (int e = 0; e < 8; ++e) ix.v[e] = (lo[e] & m0) | (lo[8 + e] & m1) | (hi[e] & m2) | (hi[8 + e] & m3);
+        return lo[0];
+    };
+    // one MFMA K step (32 occupied columns) into fresh accumulators: tile t <-> output column 8c + t
+    auto step_tile = [&](uint32_t s, const Idx &ix, f32x4_t (&t)[TPL], bool stamp) {
         uint32_t braw[8][TPL / 2];
-    };
-    auto load_idx = [&](uint32_t s, u32x4_t &lo, u32x4_t &hi) {  // this lane's 8 B-row indices of step s
-        const u32x4_t *p = reinterpret_cast<const u32x4_t *>(cols + static_cast<size_t>(s) * 32u + g * 8u);
-        lo = p[0];
-        hi = p[1];
-    };
-    auto load_step = [&](uint32_t s, const u32x4_t &lo, const u32x4_t &hi, Step &f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const uint32_t col = e < 4 ? lo[e] : hi[e - 4];
+            const uint32_t col = ix.v[e];
             // padding (0xFFFFFFFF) and lanes past N: a dropped read (zeros); the coefficients there are zero as well
             const uint32_t voff = col == 0xFFFFFFFFu ? kDropLoad : col * ldb2 + lane_off;
             const auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) f.braw[e][w] = r[w];
+            for (int w = 0; w < 4; ++w) braw[e][w] = r[w];
         }
-        f.araw = *reinterpret_cast<const u32x4_t *>(tiles + static_cast<size_t>(s) * 512u + c * 32u + g * 8u);
-    };
-    auto multiply = [&](const Step &f) {
-        const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, f.araw);
+        const u32x4_t araw = *reinterpret_cast<const u32x4_t *>(tiles + static_cast<size_t>(s) * 512u + c * 32u + g * 8u);
+        // all nine reads are on their way before the first v_perm: without this fence hipcc interleaves the operand
+        // regrouping with the loads and waits for them two at a time (four round trips instead of one)
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MISPMM_STAMPS
+        if (stamp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MISPMM_BSR_STAMP(2);
+        }
+#endif
+        const bf16x8_t afrag = __builtin_bit_cast(bf16x8_t, araw);
+        const f32x4_t zero{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < TPL / 2; ++w) {
             u32x4_t even, odd;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const uint32_t lo = f.braw[2 * p][w], hi = f.braw[2 * p + 1][w];
-                even[p] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);  // {hi.h0, lo.h0}
-                odd[p] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);   // {hi.h1, lo.h1}
+                const uint32_t l2 = braw[2 * p][w], h2 = braw[2 * p + 1][w];
+                even[p] = __builtin_amdgcn_perm(h2, l2, 0x05040100u);  // {hi.h0, lo.h0}
+                odd[p] = __builtin_amdgcn_perm(h2, l2, 0x07060302u);   // {hi.h1, lo.h1}
             }
-            acc[2 * w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, even), acc[2 * w], 0, 0, 0);
-            acc[2 * w + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, odd), acc[2 * w + 1], 0, 0, 0);
+            t[2 * w] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, even), zero, 0, 0, 0);
+            t[2 * w + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8_t, odd), zero, 0, 0, 0);
         }
     };
 
     // hop 1: this wave's slot (column list) and the extent of the block row's extra steps
-    u32x4_t ilo, ihi;
-    load_idx(R * kBsrSlots + wave, ilo, ihi);
-    const uint32_t ex0 = extraPtrs[R], ex1 = extraPtrs[R + 1];
+    Idx ix;
     // a slot past the row's step count is all padding; a used slot starts with a real column (padding only ever trails)
-    const uint32_t first = __builtin_amdgcn_readfirstlane(ilo[0]);
+    const uint32_t first = load_idx(R * kBsrSlots + wave, ix);
+    const uint32_t ex0 = extraPtrs[R], ex1 = extraPtrs[R + 1];
     MISPMM_BSR_STAMP(1);
-    if (first != 0xFFFFFFFFu) {
-        Step cur;
-        load_step(R * kBsrSlots + wave, ilo, ihi, cur);  // hop 2
-#ifdef MISPMM_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        MISPMM_BSR_STAMP(2);
-        multiply(cur);
-    }
-#ifdef MISPMM_STAMPS
-    else bstamp[2] = bstamp[1];
-#endif
-    // block rows of more than 4 steps (more than 128 occupied columns): wave w also takes extra steps w, w + 4, ...
-    for (uint32_t e = ex0 + wave; e < ex1; e += kBsrSlots) {
-        const uint32_t s = Mb * kBsrSlots + e;
-        load_idx(s, ilo, ihi);
-        Step cur;
-        load_step(s, ilo, ihi, cur);
-        multiply(cur);
-    }
-
-    // partial tiles to LDS: lane (c, g) holds rows 4g .. 4g+3, columns 8c .. 8c+7 (tile t <-> column 8c + t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float *dst = &partial[wave][g * 4 + r][c * 8];
-        *reinterpret_cast<f32x4_t *>(dst) = f32x4_t{acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        *reinterpret_cast<f32x4_t *>(dst + 4) = f32x4_t{acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
-    }
-    MISPMM_BSR_STAMP(3);
-    __syncthreads();
-    MISPMM_BSR_STAMP(4);
-    // wave w finishes rows 4w .. 4w+3: lane -> (row 4w + lane / 16, columns 8 (lane % 16) .. +7), partials added in wave order
-    const uint32_t orow = wave * 4 + (lane >> 4), ocol = (lane & 15) * 8;
-    f32x4_t s0 = *reinterpret_cast<const f32x4_t *>(&partial[0][orow][ocol]);
-    f32x4_t s1 = *reinterpret_cast<const f32x4_t *>(&partial[0][orow][ocol + 4]);
-#pragma unroll
-    for (uint32_t p = 1; p < kBsrSlots; ++p) {
-        s0 += *reinterpret_cast<const f32x4_t *>(&partial[p][orow][ocol]);
-        s1 += *reinterpret_cast<const f32x4_t *>(&partial[p][orow][ocol + 4]);
-    }
-    const uint32_t gcol = st * (16 * TPL) + ocol;
-    if (gcol < N) {
-        const size_t crow = static_cast<size_t>(R * 16 + orow) * ldc + gcol;
-        if constexpr (C_BF16) {
-            using bf2 = __bf16 __attribute__((ext_vector_type(2)));
-            u32x4_t o;
-            o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[0]), static_cast<__bf16>(s0[1])});
-            o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[2]), static_cast<__bf16>(s0[3])});
-            o[2] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[0]), static_cast<__bf16>(s1[1])});
-            o[3] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[2]), static_cast<__bf16>(s1[3])});
-            if constexpr (ST >= 0) {
-                __builtin_amdgcn_raw_buffer_store_b128(o, make_rsrc(Cv, c_bytes), static_cast<uint32_t>(crow * 2u), 0, ST);
-            } else {
-                *reinterpret_cast<u32x4_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
-            }
+    // The two roles are separate branches (wave-uniform; each executes exactly one barrier) so that the register
+    // allocator sees their lifetimes apart: wave 0 holds its tile across the barrier, waves 1..3 hold nothing across it.
+    auto slot_tile = [&](f32x4_t (&t)[TPL]) {
+        if (first != 0xFFFFFFFFu) {
+            step_tile(R * kBsrSlots + wave, ix, t, true);  // hop 2
         } else {
-            if constexpr (ST >= 0) {
-                const rsrc_t crs = make_rsrc(Cv, c_bytes);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), crs, static_cast<uint32_t>(crow * 4u), 0, ST);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s1), crs, static_cast<uint32_t>(crow * 4u + 16u), 0, ST);
-            } else {
-                float *dst = static_cast<float *>(Cv) + crow;
-                *reinterpret_cast<f32x4_t *>(dst) = s0;
-                *reinterpret_cast<f32x4_t *>(dst + 4) = s1;
+#pragma unroll
+            for (int i = 0; i < TPL; ++i) t[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifdef MISPMM_STAMPS
+            bstamp[2] = bstamp[1];
+#endif
+        }
+    };
+    if (wave != 0) {
+        {
+            f32x4_t t[TPL];
+            slot_tile(t);
+            // park the tile: lane (c, g) holds rows 4g .. 4g+3, columns 8c .. 8c+7
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *dst = &parked[wave - 1][g * 4 + r][c * 8];
+                *reinterpret_cast<f32x4_t *>(dst) = f32x4_t{t[0][r], t[1][r], t[2][r], t[3][r]};
+                *reinterpret_cast<f32x4_t *>(dst + 4) = f32x4_t{t[4][r], t[5][r], t[6][r], t[7][r]};
+            }
+        }
+        // block rows of more than 4 steps (more than 128 occupied columns): extra step i goes to wave 1 + i % 3
+        for (uint32_t e = ex0 + (wave - 1); e < ex1; e += kBsrSlots - 1) {
+            const uint32_t s = Mb * kBsrSlots + e;
+            load_idx(s, ix);
+            f32x4_t t[TPL];
+            step_tile(s, ix, t, false);
+            // the parked tile really lives in LDS between two extra steps (the clobber keeps hipcc from carrying it in
+            // 32 registers across the B reads, which would cost every launch of this kernel a resident workgroup per CU)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float *dst = &parked[wave - 1][g * 4 + r][c * 8];
+                f32x4_t a = *reinterpret_cast<f32x4_t *>(dst), b = *reinterpret_cast<f32x4_t *>(dst + 4);
+                a += f32x4_t{t[0][r], t[1][r], t[2][r], t[3][r]};
+                b += f32x4_t{t[4][r], t[5][r], t[6][r], t[7][r]};
+                *reinterpret_cast<f32x4_t *>(dst) = a;
+                *reinterpret_cast<f32x4_t *>(dst + 4) = b;
+            }
+            asm volatile("" ::: "memory");
+        }
+        MISPMM_BSR_STAMP(3);
+        __syncthreads();
+        MISPMM_BSR_STAMP(4);
+    } else {
+        f32x4_t acc[TPL];
+        slot_tile(acc);
+        MISPMM_BSR_STAMP(3);
+        __syncthreads();
+        MISPMM_BSR_STAMP(4);
+        if (ncol < N) {
+            // wave 0 adds the parked tiles in wave order and stores the block row's 16 x 128 result
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4_t s0{acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, s1{acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
+#pragma unroll
+                for (uint32_t p = 0; p < kBsrSlots - 1; ++p) {
+                    s0 += *reinterpret_cast<const f32x4_t *>(&parked[p][g * 4 + r][c * 8]);
+                    s1 += *reinterpret_cast<const f32x4_t *>(&parked[p][g * 4 + r][c * 8 + 4]);
+                }
+                const size_t crow = static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol;
+                if constexpr (C_BF16) {
+                    using bf2 = __bf16 __attribute__((ext_vector_type(2)));
+                    u32x4_t o;
+                    o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[0]), static_cast<__bf16>(s0[1])});
+                    o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[2]), static_cast<__bf16>(s0[3])});
+                    o[2] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[0]), static_cast<__bf16>(s1[1])});
+                    o[3] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[2]), static_cast<__bf16>(s1[3])});
+                    if constexpr (ST >= 0) {
+                        __builtin_amdgcn_raw_buffer_store_b128(o, make_rsrc(Cv, c_bytes), static_cast<uint32_t>(crow * 2u), 0, ST);
+                    } else {
+                        *reinterpret_cast<u32x4_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
+                    }
+                } else {
+                    if constexpr (ST >= 0) {
+                        const rsrc_t crs = make_rsrc(Cv, c_bytes);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), crs, static_cast<uint32_t>(crow * 4u), 0, ST);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s1), crs, static_cast<uint32_t>(crow * 4u + 16u), 0, ST);
+                    } else {
+                        float *dst = static_cast<float *>(Cv) + crow;
+                        *reinterpret_cast<f32x4_t *>(dst) = s0;
+                        *reinterpret_cast<f32x4_t *>(dst + 4) = s1;
+                    }
+                }
             }
         }
     }

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     const uint32_t li = lane % G;
     const uint32_t group = lane / G;
     const uint32_t col0 = slab + li * 4u;
-    const uint32_t lane_off = col0 < N ? col0 * 4u : kDropLoad;
+    const bool lane_live = col0 < N;  // lanes past the last column never fetch
+    const uint32_t lane_off = lane_live ? col0 * 4u : kDropLoad;
     const rsrc_t rsrc = make_rsrc(B, b_bytes);
     const uint32_t ldb4 = ldb * 4u;
     uint32_t row, start, end;
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
                 for (int t = 0; t < 4; ++t) {
                     const u2 pair = strip[(blk * 4u + t) * OWN + group];  // one address per lane group: LDS broadcasts
                     av[R * 4 + t] = __uint_as_float(pair[1]);
-                    bv[R * 4 + t] = buffer_load_vec<4>(rsrc, pair[0] + lane_off, 0);
+                    // (a padding entry in a dead lane: kDropLoad + kDropLoad would wrap to offset 0, a real read of B[0] whose
+                    // Inf / NaN would reach the unused partial sums and their exactness trackers -- keep the drop bit)
+                    bv[R * 4 + t] = buffer_load_vec<4>(rsrc, lane_live ? pair[0] + lane_off : kDropLoad, 0);
                 }
             };
             auto consume_block = [&](auto ring_tag) {

@@ -323,3 +323,120 @@ extern "C" int mispmm_bsr_compact_slots_bf16_host(uint32_t numBlockRows, uint32_
     if (nUsedSteps_out) *nUsedSteps_out = static_cast<uint32_t>(used);
     return MISPMM_OK;
 }
+
+// ---- row clustering (the plan order of mispmm_csr_plan_f32) ----------------------------------------------------------
+// Greedy growth of `parts` row clusters of equal size: a cluster starts from the first unassigned row and keeps taking
+// the unassigned row that shares the most columns with what the cluster already holds (lazy max-heap keyed by that
+// count).  Rows that share B rows then run on one XCD (the row-gather kernel gives an XCD a contiguous range of array
+// rows) and close together in time, so a B row fetched for one of them is still in that L2 for the others.  Columns of
+// more than 64 entries are ignored when counting (they are in every cluster anyway and would make the walk quadratic).
+// order_out[i] = the original row stored at position i; *_distinct_out = sum over the parts of the distinct columns a part
+// touches, before (contiguous parts in storage order) and after: the smaller, the fewer B rows an L2 must fetch.
+extern "C" int mispmm_csr_cluster_rows_host(uint32_t M, uint32_t K, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host,
+                                            uint32_t parts, uint32_t *order_out_host, uint64_t *natural_distinct_out,
+                                            uint64_t *clustered_distinct_out) {
+    if (!rowPtrs_host || !order_out_host) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: null pointer");
+    if (parts == 0) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: parts must be positive");
+    const uint64_t nnz = rowPtrs_host[M];
+    if (nnz != 0 && !colIdxs_host) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: colIdxs is null");
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (colIdxs_host[i] >= K) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: column index %u out of range", colIdxs_host[i]);
+    // transpose structure: the rows of every column
+    std::vector<uint32_t> colPtr(static_cast<size_t>(K) + 1, 0), colRows(nnz);
+    for (uint64_t i = 0; i < nnz; ++i) ++colPtr[colIdxs_host[i] + 1];
+    for (uint32_t c = 0; c < K; ++c) colPtr[c + 1] += colPtr[c];
+    {
+        std::vector<uint32_t> fill(colPtr.begin(), colPtr.end() - 1);
+        for (uint32_t r = 0; r < M; ++r)
+            for (uint32_t i = rowPtrs_host[r]; i < rowPtrs_host[r + 1]; ++i) colRows[fill[colIdxs_host[i]]++] = r;
+    }
+    constexpr uint32_t kMaxColumnDegree = 64;
+    const uint32_t cap = (M + parts - 1) / parts;
+    std::vector<uint8_t> assigned(M, 0);
+    std::vector<uint32_t> gain(M, 0), stamp(K, 0xFFFFFFFFu), touched;
+    std::vector<std::pair<uint32_t, uint32_t>> heap;  // (gain, row), max-heap; stale entries are skipped when popped
+    uint32_t next_seed = 0, placed = 0;
+    for (uint32_t p = 0; p < parts && placed < M; ++p) {
+        heap.clear();
+        for (uint32_t r : touched) gain[r] = 0;
+        touched.clear();
+        uint32_t size = 0;
+        while (size < cap && placed < M) {
+            uint32_t r = 0xFFFFFFFFu;
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const auto top = heap.back();
+                heap.pop_back();
+                if (!assigned[top.second] && gain[top.second] == top.first) {
+                    r = top.second;
+                    break;
+                }
+            }
+            if (r == 0xFFFFFFFFu) {  // nothing shares a column with the cluster (or it is empty): next row in storage order
+                while (next_seed < M && assigned[next_seed]) ++next_seed;
+                r = next_seed;
+            }
+            assigned[r] = 1;
+            order_out_host[placed++] = r;
+            ++size;
+            for (uint32_t i = rowPtrs_host[r]; i < rowPtrs_host[r + 1]; ++i) {
+                const uint32_t c = colIdxs_host[i];
+                if (stamp[c] == p) continue;  // the cluster already holds this column
+                stamp[c] = p;
+                if (colPtr[c + 1] - colPtr[c] > kMaxColumnDegree) continue;
+                for (uint32_t j = colPtr[c]; j < colPtr[c + 1]; ++j) {
+                    const uint32_t r2 = colRows[j];
+                    if (assigned[r2]) continue;
+                    if (gain[r2]++ == 0) touched.push_back(r2);
+                    heap.emplace_back(gain[r2], r2);
+                    std::push_heap(heap.begin(), heap.end());
+                }
+            }
+        }
+    }
+    // the figure of merit, before and after
+    auto distinct = [&](auto row_at) {
+        std::vector<uint32_t> seen(K, 0xFFFFFFFFu);
+        uint64_t total = 0;
+        for (uint32_t p = 0; p < parts; ++p)
+            for (uint32_t i = p * cap; i < std::min<uint64_t>(M, static_cast<uint64_t>(p + 1) * cap); ++i) {
+                const uint32_t r = row_at(i);
+                for (uint32_t e = rowPtrs_host[r]; e < rowPtrs_host[r + 1]; ++e)
+                    if (seen[colIdxs_host[e]] != p) {
+                        seen[colIdxs_host[e]] = p;
+                        ++total;
+                    }
+            }
+        return total;
+    };
+    if (natural_distinct_out) *natural_distinct_out = distinct([](uint32_t i) { return i; });
+    if (clustered_distinct_out) *clustered_distinct_out = distinct([&](uint32_t i) { return order_out_host[i]; });
+    return MISPMM_OK;
+}
+
+// The arrays of the CSR whose row i is row order[i] of the input (order = a permutation of 0 .. M-1): what
+// mispmm_csr_plan_f32 multiplies from, with rowMap = order.
+extern "C" int mispmm_csr_permute_rows_host(uint32_t M, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host, const float *vals_host,
+                                            const uint32_t *order_host, uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host,
+                                            float *vals_out_host) {
+    if (!rowPtrs_host || !order_host || !rowPtrs_out_host) return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: null pointer");
+    const uint64_t nnz = rowPtrs_host[M];
+    if (nnz != 0 && (!colIdxs_host || !vals_host || !colIdxs_out_host || !vals_out_host))
+        return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: null entry arrays");
+    std::vector<uint8_t> seen(M, 0);
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < M; ++i) {
+        const uint32_t r = order_host[i];
+        if (r >= M || seen[r]) return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: order is not a permutation (entry %u = %u)", i, r);
+        seen[r] = 1;
+        rowPtrs_out_host[i] = static_cast<uint32_t>(at);
+        const uint32_t len = rowPtrs_host[r + 1] - rowPtrs_host[r];
+        if (len) {
+            std::memcpy(colIdxs_out_host + at, colIdxs_host + rowPtrs_host[r], static_cast<size_t>(len) * sizeof(uint32_t));
+            std::memcpy(vals_out_host + at, vals_host + rowPtrs_host[r], static_cast<size_t>(len) * sizeof(float));
+        }
+        at += len;
+    }
+    rowPtrs_out_host[M] = static_cast<uint32_t>(at);
+    return MISPMM_OK;
+}

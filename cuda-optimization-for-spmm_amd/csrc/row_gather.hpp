@@ -68,14 +68,19 @@ template <> struct BatchArg<true> {
 };
 
 template <int G, int VEC, class Acc, bool CBUF, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
-          bool BATCHED = false>
+          bool BATCHED = false, bool MAPPED = false>
 __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
-    uint32_t M, uint32_t rb_chunk, uint32_t log2p, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
+    // tiling: bits 0..7 log2 of the row parts P of the XCD grid; bits 8..31 (CsrRows only) a GUESSED row length w, given
+    // when nnz == M * w: the wave fetches its first (col, val) entries from r * w while the row pointers are still on
+    // their way and keeps them if the pointers confirm the guess (see the rolling body)
+    uint32_t M, uint32_t rb_chunk, uint32_t tiling, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
     const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
-    const float *__restrict__ B_one, float *__restrict__ C_one, uint32_t c_bytes, uint32_t ldc, BatchArg<BATCHED> batch
+    const float *__restrict__ B_one, float *__restrict__ C_one, uint32_t c_bytes, uint32_t ldc,
+    // rows stored in a plan order (mispmm_csr_plan_f32): array row i is row rowMap[i] of C; NULL = identity
+    const uint32_t *__restrict__ rowMap, BatchArg<BATCHED> batch
 #ifdef MISPMM_STAMPS
     , uint32_t stamp_launch  // which of the last kStampLaunches launches this is: each keeps its own stamp records
 #endif
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     using vec_t = typename VecOf<VEC>::type;
     const uint32_t lane = threadIdx.x % G;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t log2p = tiling & 0xFFu;
     const uint32_t p = xcd & ((1u << log2p) - 1u), q = xcd >> log2p;
     const uint32_t row = (p * rb_chunk + slot) * GROUPS + threadIdx.x / G;
     const bool row_ok = row < M;
@@ -107,10 +113,35 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
     const bool col_ok = col0 < min(N, (q + 1) * cols_per_part);
     size_t row_base = 0;
     uint32_t row_len = 0;
-    if (row_ok) rows.extent(row, row_base, row_len);
+    // CSR: the two row pointers are read unconditionally (row clamped) and only RESOLVED into (row_base, row_len) where a
+    // path first needs them -- inside an `if (row_ok)` block hipcc waits for them on the spot, which would put the bet
+    // on uniform rows (rolling body) behind the very hop it is meant to overlap
+    uint32_t ptr_lo = 0, ptr_hi = 0;
+    if constexpr (std::is_same_v<Rows, CsrRows>) {
+        const uint32_t rr = min(row, M - 1u);
+        ptr_lo = rows.rowPtrs[rr];
+        ptr_hi = rows.rowPtrs[rr + 1];
+    } else {
+        if (row_ok) rows.extent(row, row_base, row_len);
+    }
+    auto resolve_extent = [&] {
+        if constexpr (std::is_same_v<Rows, CsrRows>) {
+            row_base = ptr_lo;
+            row_len = row_ok ? ptr_hi - ptr_lo : 0u;
+        }
+    };
     typename Acc::T acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0;
+    // where this group's row goes in C: read behind the row's first (col, val) fetch, needed only by the final store
+    uint32_t out_row = row;
+    // (MAPPED is a template parameter on purpose: as a run-time test of the pointer it cost every launch of the unmapped
+    // kernel 0.2 us on the headline -- a kernarg wait and a branch in front of the first B reads)
+    auto load_out_row = [&] {
+        if constexpr (MAPPED) {
+            if (row_ok) out_row = rowMap[row];
+        }
+    };
     const rsrc_t rsrc = make_rsrc(B, b_bytes);
     const uint32_t lane_off = col_ok ? col0 * 4u : kDropLoad;  // lanes past the column part never fetch
     const uint32_t ldb4 = ldb * 4u;
@@ -178,7 +209,31 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                 }
             }
         };
-        if (row_len != 0) fetch_super(0);
+        if constexpr (std::is_same_v<Rows, CsrRows>) {
+            // A CSR with nnz == M * w may well have w entries in EVERY row (simplicial boundary matrices, regular graphs,
+            // ELL-shaped exports: the headline matrix through the general entry point).  Bet on it: fetch the first entries
+            // from r * w right behind the row-pointer reads instead of behind their result -- one dependent memory hop less
+            // (n4c6-b13 without the uniform-row hint: 3.67 -> see profiles/r3) -- and fetch again only if some row of the
+            // wave turns out different.  The guessed positions are in range because M * w == nnz; results never depend on
+            // the guess.
+            const uint32_t guess = tiling >> 8;
+            if (guess != 0) {
+                row_base = static_cast<size_t>(row) * guess;
+                row_len = row_ok ? guess : 0u;
+                if (row_len != 0) fetch_super(0);
+                const size_t bet_base = row_base;
+                const uint32_t bet_len = row_len;
+                resolve_extent();  // the first use of the row pointers: behind the issue of the guessed fetch
+                const bool hit = __all(!row_ok || (row_base == bet_base && row_len == bet_len));
+                if (!hit && row_len != 0) fetch_super(0);
+            } else {
+                resolve_extent();
+                if (row_len != 0) fetch_super(0);
+            }
+        } else {
+            if (row_len != 0) fetch_super(0);
+        }
+        load_out_row();
 #ifdef MISPMM_X_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -260,17 +315,24 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
                 // ragged rows: the body is as long as the longest row of the wave needs, in steps of two slots (each
                 // dropped slot still costs its broadcasts, its load issue and its sums: the general entry point ran
                 // 3.88 us on the 14-entry rows of n4c6-b13 with the 16-slot body against 3.55 us behind the uniform hint)
+#ifdef MISPMM_X_FEWBODIES
+                // experiment: two body lengths instead of four (code size of the general kernel vs dropped slots)
+                if (!live_from(std::integral_constant<int, 14>{})) roll(std::integral_constant<int, 14>{});
+                else roll(std::integral_constant<int, 16>{});
+#else
                 if (!live_from(std::integral_constant<int, 10>{})) roll(std::integral_constant<int, 10>{});
                 else if (!live_from(std::integral_constant<int, 12>{})) roll(std::integral_constant<int, 12>{});
                 else if (!live_from(std::integral_constant<int, 14>{})) roll(std::integral_constant<int, 14>{});
                 else roll(std::integral_constant<int, 16>{});
+#endif
             } else {
                 roll(std::integral_constant<int, SC>{});
             }
         }
-    } else if (!__any(row_len > static_cast<uint32_t>(U))) {
+    } else if (resolve_extent(), !__any(row_len > static_cast<uint32_t>(U))) {
         // Every row of this wave fits one batch: one (col, val) fetch, U B reads in flight, one pass of
         // multiply-adds.  Wave-uniform branch.
+        load_out_row();
         if (row_len != 0) {
             uint32_t my_off;
             float my_val;
@@ -289,6 +351,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
         uint32_t nxt_off = 0;
         float nxt_val = 0.f;
         if (row_len != 0) fetch(row_base + min(lane, row_len - 1), nxt_off, nxt_val);
+        load_out_row();
         for (uint32_t base = 0; base < row_len; base += G) {
             const uint32_t cnt = min(static_cast<uint32_t>(G), row_len - base);
             const uint32_t my_off = nxt_off;
@@ -312,9 +375,9 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gath
 #pragma unroll
         for (int v = 0; v < VEC; ++v) vec_set<VEC>(out, v, Acc::finish(acc[v]));
         if constexpr (CBUF) {  // buffer stores with the library's C store policy (non-temporal); else plain global stores
-            buffer_store_vec_c<VEC>(make_rsrc(C, c_bytes), (row * ldc + col0) * 4u, out);
+            buffer_store_vec_c<VEC>(make_rsrc(C, c_bytes), (out_row * ldc + col0) * 4u, out);
         } else {
-            store_vec<VEC>(C + static_cast<size_t>(row) * ldc + col0, out);
+            store_vec<VEC>(C + static_cast<size_t>(out_row) * ldc + col0, out);
         }
     }
 #ifdef MISPMM_STAMPS
@@ -351,10 +414,17 @@ struct RowGatherArgs {
     float *C;
     uint32_t ldc;
     uint32_t mean_row_len = 0;  // nnz / M when the caller knows it (CSR, COO); 0 = unknown
+    const uint32_t *rowMap = nullptr;  // rows stored in a plan order: array row i is row rowMap[i] of C (NULL = identity)
+    uint32_t row_len_guess = 0;        // CsrRows: nnz / M when nnz == M * (nnz / M), else 0 (the kernel's bet on uniform rows)
     uint32_t batch = 0;         // > 0: B / C are ignored, product i uses B_list[i] / C_list[i] (host arrays), i < batch <= kMaxBatch
     const float *const *B_list = nullptr;
     float *const *C_list = nullptr;
 };
+
+// the row length the general CSR kernel bets on: nnz / M when the entries divide evenly over the rows, else 0 (no bet)
+inline uint32_t uniform_guess(uint32_t M, uint64_t nnz) {
+    return (M != 0 && nnz != 0 && nnz % M == 0) ? static_cast<uint32_t>(nnz / M) : 0u;
+}
 
 // P x Q XCD grid and the C store flavour (`sc1`, name kept from round 2: C through buffer stores with the policy of
 // spmm_common.hpp -- non-temporal -- instead of plain global stores).  MISPMM_CSR_TILING="P,Q" and MISPMM_STORE_SC1=0/1 override
@@ -417,8 +487,10 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
     dim3 grid(8u * rb_chunk, ceil_div(cols_per_part, G * VEC));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(a.K) * a.ldb * 4u);
     const uint64_t c_bytes = static_cast<uint64_t>(a.M) * a.ldc * 4u;
-    note_kernel("row_gather<G%d,V%d,%s,%s,B%d,U%d,%s,S%d> xcd %ux%u%s", G, VEC, acc_tag<Acc>(), rows_tag<Rows>(), BLOCK, UMAX,
-                ROLL ? "roll" : "batch", SLOTS, 1u << t.log2p, t.q, a.batch ? " batched" : "");
+    static const bool guess_on = knob_int("MISPMM_ROW_GUESS", 1) != 0;  // MISPMM_ROW_GUESS=0: no bet on uniform rows (measurement aid)
+    const uint32_t tiling = t.log2p | ((std::is_same_v<Rows, CsrRows> && ROLL && guess_on && a.row_len_guess < (1u << 24)) ? a.row_len_guess << 8 : 0u);
+    note_kernel("row_gather<G%d,V%d,%s,%s,B%d,U%d,%s,S%d> xcd %ux%u%s%s", G, VEC, acc_tag<Acc>(), rows_tag<Rows>(), BLOCK, UMAX,
+                ROLL ? "roll" : "batch", SLOTS, 1u << t.log2p, t.q, a.batch ? " batched" : "", a.rowMap ? " plan-order" : "");
 #ifdef MISPMM_STAMPS
     static uint32_t stamp_counter = 0;
     const uint32_t stamp_launch = stamp_counter++ % kStampLaunches;
@@ -434,9 +506,14 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
                 arg.p.c[i] = a.C_list[i < a.batch ? i : 0];
             }
             grid.z = a.batch;
-            hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS, true>), grid, dim3(BLOCK), 0, a.stream,
-                               a.M, rb_chunk, t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, nullptr, nullptr,
-                               static_cast<uint32_t>(c_bytes), a.ldc, arg MISPMM_STAMP_ARG);
+            if (a.rowMap)
+                hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS, true, true>), grid, dim3(BLOCK), 0, a.stream,
+                                   a.M, rb_chunk, tiling, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, nullptr, nullptr,
+                                   static_cast<uint32_t>(c_bytes), a.ldc, a.rowMap, arg MISPMM_STAMP_ARG);
+            else
+                hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS, true>), grid, dim3(BLOCK), 0, a.stream,
+                                   a.M, rb_chunk, tiling, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, nullptr, nullptr,
+                                   static_cast<uint32_t>(c_bytes), a.ldc, nullptr, arg MISPMM_STAMP_ARG);
             return;
         }
     }
@@ -450,13 +527,25 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
         }
         return;
     }
+    if constexpr (ROLL && BLOCK == 128 && UMAX == 8 && G <= 16 && VEC == 4) {
+        if (a.rowMap) {  // plan order: the mapped form of the main body only (row_gather_supports_map)
+            hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS, false, true>), grid, dim3(BLOCK), 0, a.stream,
+                               a.M, rb_chunk, tiling, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
+                               static_cast<uint32_t>(c_bytes), a.ldc, a.rowMap, BatchArg<false>{} MISPMM_STAMP_ARG);
+            return;
+        }
+    }
+    if (a.rowMap) {  // only reachable through a measurement knob that forces another body: never multiply unmapped
+        fprintf(stderr, "mispmm: the row-gather body picked by the tuning knobs has no row-mapped form\n");
+        abort();
+    }
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
-                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
-                           static_cast<uint32_t>(c_bytes), a.ldc, BatchArg<false>{} MISPMM_STAMP_ARG);
+                           tiling, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C,
+                           static_cast<uint32_t>(c_bytes), a.ldc, a.rowMap, BatchArg<false>{} MISPMM_STAMP_ARG);
     else
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, false, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
-                           t.log2p, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc, BatchArg<false>{} MISPMM_STAMP_ARG);
+                           tiling, cols_per_part, a.N, a.ldb, rows, a.colIdxs, a.vals, b_bytes, a.B, a.C, 0u, a.ldc, a.rowMap, BatchArg<false>{} MISPMM_STAMP_ARG);
 #undef MISPMM_STAMP_ARG
 }
 
@@ -507,6 +596,14 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
     else if (block == 256) launch_row_gather_b<G, VEC, Acc, Rows, 256, 8>(a, rows, t);
     else if (umax == 16) launch_row_gather_b<G, VEC, Acc, Rows, 128, 16>(a, rows, t);
     else launch_row_gather_b<G, VEC, Acc, Rows, 128, 8>(a, rows, t);
+}
+
+// Which shapes have a row-mapped (plan order) form: the main rolling body -- 16-byte vectors, column parts of whole
+// 32-column groups, C below 2 GiB (buffer stores), short rows.  mispmm_csr_plan_f32 declines everything else.
+inline bool row_gather_supports_map(uint32_t M, uint32_t N, uint32_t ldc, int vec, uint32_t mean_row_len) {
+    if (vec != 4 || static_cast<uint64_t>(M) * ldc * 4u > 0x7FFFFFFFull || mean_row_len >= 24) return false;
+    const XcdTiling t = xcd_tiling(N, vec);
+    return t.sc1 && (N / t.q) % 32 == 0;
 }
 
 // needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check

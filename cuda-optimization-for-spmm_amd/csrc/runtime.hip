@@ -104,6 +104,12 @@ int mispmm_device_info(int ordinal, char *name, int *cu_count, size_t *hbm_bytes
     return MISPMM_OK;
 }
 
+int mispmm_device_bus_id(int ordinal, char *bus_id, int len) {
+    if (!bus_id || len < 16) return fail(MISPMM_ERR_INVALID_ARG, "device_bus_id: buffer of at least 16 bytes needed");
+    MISPMM_HIP_TRY(hipDeviceGetPCIBusId(bus_id, len, ordinal));
+    return MISPMM_OK;
+}
+
 int mispmm_malloc(void **dev_ptr, size_t bytes) {
     if (!dev_ptr) return fail(MISPMM_ERR_INVALID_ARG, "dev_ptr is null");
     *dev_ptr = nullptr;

@@ -574,7 +574,8 @@ static void launch_csr(const CsrArgs &a, int kernel, int vec) {
         return;
     }
     if (kernel == 5 && !wide) {
-        const RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc, a.M ? a.nnz / a.M : 0u};
+        RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc, a.M ? a.nnz / a.M : 0u};
+        ga.row_len_guess = uniform_guess(a.M, a.nnz);
         launch_row_gather_auto<Acc>(ga, CsrRows{a.rowPtrs}, vec);
         return;
     }
@@ -721,6 +722,7 @@ extern "C" int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t
         ga.batch = std::min(kMaxBatch, batch - first);
         ga.B_list = B_list_host + first;
         ga.C_list = C_list_host + first;
+        ga.row_len_guess = uniform_guess(M, nnz);
         if (uniformRowNnz) {
             if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{uniformRowNnz}, vec);
             else launch_row_gather_auto<AccFast>(ga, UniformRows{uniformRowNnz}, vec);
@@ -728,6 +730,61 @@ extern "C" int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t
             if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, CsrRows{rowPtrs}, vec);
             else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
         }
+        MISPMM_LAUNCH_CHECK();
+    }
+    return MISPMM_OK;
+}
+
+// A CSR stored in a PLAN order (rows permuted once at upload, e.g. by mispmm_csr_cluster_rows_host so that rows which
+// read the same B rows run close together in time and on the same XCD): array row i produces row rowMap[i] of C.  Always the
+// row-gather kernel (the only one that scatters its rows); one launch per 16 operands where the batched form exists.
+extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                   const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, const uint32_t *rowMap,
+                                   uint32_t batch, const float *const *B_list_host, uint32_t N, uint32_t ldb,
+                                   float *const *C_list_host, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_plan: unknown accumulate mode %d", acc_mode);
+    if (batch == 0 || M == 0 || N == 0) return MISPMM_OK;
+    if (!B_list_host || !C_list_host) return fail(MISPMM_ERR_INVALID_ARG, "csr_plan: null operand list");
+    if (!rowPtrs && uniformRowNnz == 0) return fail(MISPMM_ERR_INVALID_ARG, "csr_plan: rowPtrs is null");
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_plan: colIdxs or vals is null");
+    int vec = 4;
+    for (uint32_t i = 0; i < batch; ++i) {
+        if (int s = check_dense_args(B_list_host[i], N, ldb, C_list_host[i], ldc)) return s;
+        vec = std::min(vec, pick_vec(B_list_host[i], ldb, C_list_host[i], ldc, N));
+    }
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
+        return fail(MISPMM_ERR_UNSUPPORTED, "csr_plan: B of 2 GiB or more: multiply from the unpermuted arrays (mispmm_csr_f32)");
+    if (rowMap && !row_gather_supports_map(M, N, ldc, vec, uniformRowNnz ? uniformRowNnz : nnz / M))
+        return fail(MISPMM_ERR_UNSUPPORTED, "csr_plan: the row-mapped kernel takes 16-byte-aligned operands with N a multiple of 32 "
+                                            "(per XCD column part), C below 2 GiB and short rows: multiply from the unpermuted arrays");
+    const bool batched_ok = vec == 4 && static_cast<uint64_t>(M) * ldc * 4u <= 0x7FFFFFFFull && (N / xcd_tiling(N, vec).q) % 32 == 0 &&
+                            !(uniformRowNnz == 0 && nnz / M >= 24);
+    auto launch = [&](RowGatherArgs &ga) {
+        ga.rowMap = rowMap;
+        ga.row_len_guess = uniform_guess(M, nnz);
+        if (uniformRowNnz) {
+            if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{uniformRowNnz}, vec);
+            else launch_row_gather_auto<AccFast>(ga, UniformRows{uniformRowNnz}, vec);
+        } else {
+            if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, CsrRows{rowPtrs}, vec);
+            else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
+        }
+    };
+    if (batch > 1 && batched_ok) {
+        for (uint32_t first = 0; first < batch; first += kMaxBatch) {
+            RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, nullptr, N, ldb, nullptr, ldc, M ? nnz / M : 0u};
+            ga.batch = std::min(kMaxBatch, batch - first);
+            ga.B_list = B_list_host + first;
+            ga.C_list = C_list_host + first;
+            launch(ga);
+            MISPMM_LAUNCH_CHECK();
+        }
+        return MISPMM_OK;
+    }
+    for (uint32_t i = 0; i < batch; ++i) {
+        RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B_list_host[i], N, ldb, C_list_host[i], ldc, M ? nnz / M : 0u};
+        launch(ga);
         MISPMM_LAUNCH_CHECK();
     }
     return MISPMM_OK;

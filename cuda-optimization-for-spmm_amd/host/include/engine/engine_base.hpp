@@ -20,6 +20,7 @@ struct EngineOptions {
     bool vendorCheck = true; // run (and compare!) the rocSPARSE SpMM where the format supports it
     int gpus = 0;            // > 0 (`--gpus n`): also run the CSR SpMM row-sharded over n devices of this node
     int gatherMode = 1;      // mispmm_gather_mode of that run (default MISPMM_GATHER_TO_FIRST)
+    int batch = 0;           // > 1 (`--batch n`, CSR): also multiply n dense operands by A in ONE launch (mispmm_csr_batch_f32)
     bool bf16 = false;       // `--dtype bf16` (BSR with 16-row blocks): also run the bf16 MFMA kernels (BASELINE config 4)
 };
 EngineOptions &engineOptions();

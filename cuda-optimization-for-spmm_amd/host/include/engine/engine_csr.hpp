@@ -21,6 +21,12 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
 template <typename DT, typename MT, typename AccT>
 bool spmmCSRMultiGpu(int ngpus, int gatherMode, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref);
 
+// `--batch n`: n dense operands (n device copies of B in buffers of their own) multiplied by the device matrix in ONE
+// launch (mispmm_csr_batch_f32, or mispmm_csr_plan_f32 where the clustered row order pays); every result is checked
+// against `ref`; one record with an extra "batch" key whose steady-state figures are per product.
+template <typename DT, typename MT, typename AccT>
+bool spmmCSRBatched(int batch, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref);
+
 #define CUSPMM_DECLARE_CSR_WRAPPER(N)                                                                          \
     template <typename DT, typename MT, typename AccT>                                                         \
     DenseMatrix<DT, MT> *spmmCSRWrapper##N(SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b,                 \

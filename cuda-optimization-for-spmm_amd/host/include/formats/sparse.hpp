@@ -29,6 +29,13 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     // list mispmm_csr_split_f32 walks -- rows longest first, the longest as 4 chunks each (mispmm_csr_spans_by_length_host)
     MT *rowSpans = nullptr;
     MT numSpans = 0;
+    // device copies of a short-row matrix of 1024 rows or more whose rows cluster (mispmm_csr_cluster_rows_host cuts the
+    // distinct columns per row part by 10 % or more): the same matrix with its rows in the clustered order, for
+    // mispmm_csr_plan_f32 -- planRowMap[i] = the C row that array row i produces
+    MT *planRowPtrs = nullptr;
+    MT *planColIdxs = nullptr;
+    _dataT *planData = nullptr;
+    MT *planRowMap = nullptr;
 
     SparseMatrixCSR() = default;
     explicit SparseMatrixCSR(std::string filePath);

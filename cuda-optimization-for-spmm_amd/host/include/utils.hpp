@@ -28,6 +28,8 @@ struct SteadyStats {
     double rooflineFrac = 0; // hbmGBps / 8000 (MI355X HBM3E peak; times ngpus for a sharded run)
     int ngpus = 0;           // > 0: the record is a row-sharded multi-GPU run over this many devices
     const char *dtype = nullptr;  // set when the kernel did not compute in the engine's DT (e.g. "bf16")
+    int batch = 0;           // > 0 (`--batch n`): one launch multiplied this many dense operands; times are per product
+    std::string kernelTag;   // mispmm_last_kernel() of the launch the record times: several kernel ids may share one device kernel
 };
 
 // `ordering`: 0 = ROW_MAJOR.  `kernelNum`: 0 = sequential CPU engine, -1 = vendor library.

@@ -54,6 +54,13 @@ void runEngine(EngT *engine, typename EngT::MataT *a, typename EngT::MatbT *b, f
                                                                               b, cpuRes);
         }
 
+        // 3c. `--batch n`: n dense operands multiplied by A in one launch (CSR; the reference multiplies by one dense.in per
+        //     process, src/main.cu:185) -- what a caller with several right-hand sides gets for the launch boundary paid once
+        if constexpr (std::is_same_v<ma_t, SparseMatrixCSR<typename ma_t::DT, typename ma_t::MT>>) {
+            if (engineOptions().batch > 1)
+                spmmCSRBatched<typename ma_t::DT, typename ma_t::MT, double>(engineOptions().batch, da, db, cpuRes);
+        }
+
         // 4. vendor library, timed AND compared (the reference hard-codes correct = 1, engine.cpp:47-55)
         if (engine->SUPPORT_CUSPARSE && engineOptions().vendorCheck) {
             mb_t *dc = new mb_t(a->numRows, b->numCols, true, ORDERING::ROW_MAJOR);

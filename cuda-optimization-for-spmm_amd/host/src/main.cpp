@@ -14,6 +14,8 @@
 //   --dtype <t>      fp32 (default) | bf16: with --bsr and 16-row blocks also run the bf16 MFMA kernels (BASELINE config 4)
 //   --gpus <n>       (--csr) also run the product row-sharded over n GPUs of this node: B replicated, C row slabs
 //                    gathered over xGMI; --gather first|peer|rccl|none picks how (default first = into device 0)
+//   --batch <n>      (--csr) also multiply n dense operands (n device copies of B) by A in ONE launch
+//                    (mispmm_csr_batch_f32): one more record, key "batch", steady-state figures per product
 #include <getopt.h>
 
 #include <cstdlib>
@@ -42,6 +44,7 @@ static void printHelp(const char *prog) {
               << "  --save <file>   Save the last result matrix\n"
               << "  --dtype <t>     fp32 | bf16 (with --bsr, 16-row blocks: bf16 MFMA kernels as well)\n"
               << "  --gpus <n>      With --csr: also run row-sharded over n GPUs (B replicated, C slabs gathered)\n"
+              << "  --batch <n>     With --csr: also multiply n dense operands by A in ONE launch (record key \"batch\")\n"
               << "  --gather <how>  first | peer | rccl | none (default first: slabs copied into device 0)\n"
               << "  -h, --help      Display this help message\n";
 }
@@ -51,7 +54,7 @@ int main(int argc, char *argv[]) {
     bool wantCoo = false, wantCsr = false, wantBsr = false, wantEll = false, cpuOnly = false, vendorBsr = false;
     int device = 0;
     long synthCols = 0;
-    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE, OPT_VENDORBSR, OPT_GPUS, OPT_GATHER, OPT_DTYPE };
+    enum { OPT_DEVICE = 1000, OPT_SYNTH, OPT_ITERS, OPT_ACC, OPT_CPU, OPT_NOVENDOR, OPT_SAVE, OPT_VENDORBSR, OPT_GPUS, OPT_GATHER, OPT_DTYPE, OPT_BATCH };
     const option longOpts[] = {{"bsr", no_argument, nullptr, 'B'},           {"coo", no_argument, nullptr, 'O'},
                                {"csr", no_argument, nullptr, 'S'},           {"ell", no_argument, nullptr, 'E'},
                                {"cuda", no_argument, nullptr, 'U'},          {"help", no_argument, nullptr, 'h'},
@@ -64,6 +67,7 @@ int main(int argc, char *argv[]) {
                                {"save", required_argument, nullptr, OPT_SAVE},
                                {"vendor-bsr", no_argument, nullptr, OPT_VENDORBSR},
                                {"gpus", required_argument, nullptr, OPT_GPUS},
+                               {"batch", required_argument, nullptr, OPT_BATCH},
                                {"gather", required_argument, nullptr, OPT_GATHER},
                                {"dtype", required_argument, nullptr, OPT_DTYPE},
                                {nullptr, 0, nullptr, 0}};
@@ -99,6 +103,7 @@ int main(int argc, char *argv[]) {
                 break;
             }
             case OPT_GPUS: cuspmm::engineOptions().gpus = std::atoi(optarg); break;
+            case OPT_BATCH: cuspmm::engineOptions().batch = std::atoi(optarg); break;
             case OPT_GATHER: {
                 const std::string g = optarg;
                 if (g == "none") cuspmm::engineOptions().gatherMode = MISPMM_GATHER_NONE;

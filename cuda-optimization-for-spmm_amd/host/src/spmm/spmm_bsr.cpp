@@ -90,7 +90,9 @@ inline float bf16Round(float x) {
 // `--dtype bf16` (BASELINE.json config 4; the reference has no bf16): A and B rounded to bf16, fp32 accumulate on
 // v_mfma_f32_16x16x32_bf16.  The self-check reference is the sequential engine run on the ROUNDED operands, so
 // `correct` judges the kernels' arithmetic and not the rounding of the inputs.  Two records with "dtype":"bf16":
-// kernelType 4 = column-compacted block rows (mispmm_bsrc_bf16), 5 = one B panel per block (mispmm_bsr_bf16).
+// kernelType 6 = column-compacted block rows in 4 step slots, a workgroup per block row (mispmm_bsrc_slots_bf16: config
+// 4's kernel from round 3), 4 = the same operand walked by one wave per block row (mispmm_bsrc_bf16), 5 = one B panel
+// per block (mispmm_bsr_bf16).  hbmGBps / rooflineFrac of each record count the bytes THAT kernel must move.
 template <typename DT, typename MT>
 void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *db) {
     if constexpr (!std::is_same_v<DT, float>) {
@@ -125,13 +127,32 @@ void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseM
         copyBuffer(dsp, true, sp.data(), false, sp.size() * 4);
         copyBuffer(dcl, true, cl.data(), false, cl.size() * 4);
         copyBuffer(dtl, true, tl.data(), false, tl.size() * 2);
+        // the same occupied columns in fixed step slots (4 per block row + extra steps)
+        uint32_t nSlotSteps = 0, nUsed = 0;
+        mispmmCheckError(mispmm_bsr_compact_slots_bf16_host(a->numBlockRows, a->blockRowSize, a->blockColSize, a->numBlocks, a->blockRowPtrs,
+                                                            a->blockColIdxs, a->data, &nSlotSteps, &nUsed, nullptr, nullptr, nullptr));
+        std::vector<uint32_t> ep((size_t)a->numBlockRows + 1), scl((size_t)(nSlotSteps ? nSlotSteps : 1) * 32);
+        std::vector<uint16_t> stl((size_t)(nSlotSteps ? nSlotSteps : 1) * 512);
+        mispmmCheckError(mispmm_bsr_compact_slots_bf16_host(a->numBlockRows, a->blockRowSize, a->blockColSize, a->numBlocks, a->blockRowPtrs,
+                                                            a->blockColIdxs, a->data, &nSlotSteps, &nUsed, ep.data(), scl.data(), stl.data()));
+        uint32_t *dep = allocateBuffer<uint32_t>(ep.size(), true), *dscl = allocateBuffer<uint32_t>(scl.size(), true);
+        uint16_t *dstl = allocateBuffer<uint16_t>(stl.size(), true);
+        copyBuffer(dep, true, ep.data(), false, ep.size() * 4);
+        copyBuffer(dscl, true, scl.data(), false, scl.size() * 4);
+        copyBuffer(dstl, true, stl.data(), false, stl.size() * 2);
         const double n = N;
+        const double denseBC = a->numCols * n * 2 + a->numRows * n * 4;  // B bf16 + C fp32
         WrapperShape shape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * da->nzCount * n,
-                           a->numElements * 2.0 + a->numBlocks * 4.0 + (a->numBlockRows + 1.0) * 4 + a->numCols * n * 2 + a->numRows * n * 4};
+                           nSlotSteps * 128.0 + nUsed * 1024.0 + (a->numBlockRows + 1.0) * 4 + denseBC};
         shape.dtype = "bf16";
+        delete runWrapper<DT, MT>(shape, 6, db, &ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            return mispmm_bsrc_slots_bf16(stream, a->numBlockRows, K, nSlotSteps, dep, dscl, dstl, b16, N, N, c, ldc, 0);
+        });
+        shape.algorithmicBytes = nSteps * 1152.0 + (a->numBlockRows + 1.0) * 4 + denseBC;
         delete runWrapper<DT, MT>(shape, 4, db, &ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
             return mispmm_bsrc_bf16(stream, a->numBlockRows, K, nSteps, dsp, dcl, dtl, b16, N, N, c, ldc, 0);
         });
+        shape.algorithmicBytes = a->numElements * 2.0 + a->numBlocks * 4.0 + (a->numBlockRows + 1.0) * 4 + denseBC;
         if (a->blockColSize == 16) {
             delete runWrapper<DT, MT>(shape, 5, db, &ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
                 return mispmm_bsr_bf16(stream, a->numBlockRows, K, 16, 16, a->numBlocks, da->blockRowPtrs, da->blockColIdxs, blocks16, b16,
@@ -143,6 +164,9 @@ void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseM
         releaseBuffer(dsp, true);
         releaseBuffer(dcl, true);
         releaseBuffer(dtl, true);
+        releaseBuffer(dep, true);
+        releaseBuffer(dscl, true);
+        releaseBuffer(dstl, true);
     }
 }
 

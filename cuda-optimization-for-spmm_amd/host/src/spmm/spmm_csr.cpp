@@ -1,4 +1,8 @@
 // CSR: sequential CPU engine (kernel 0) and the HIP wrapper.
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
 #include "engine/engine_csr.hpp"
 #include "engine/wrapper_common.hpp"
 
@@ -41,6 +45,17 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
                                  a->numNonZero * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
         const int acc = accModeOf<AccT>();
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
+            // rows in the clustered order copy2Device found, where the slice of B one XCD reads (every B row x its column part
+            // of N / 8 columns) does not fit the 4 MiB L2 -- measured: n4c6-b13 x K=512 13.64 -> 12.93 us, no gain at
+            // K=128, a loss at K=256 (profiles/r3/plan_order.log).  Same bits: every row keeps its entries in storage order.
+            const bool planPays = b->numCols % 512 == 0 && (uint64_t)a->numCols * (b->numCols / 8) * 4 > (4ull << 20);
+            if (a->planRowMap && planPays && (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5)) {
+                const float *bl[1] = {b->data};
+                float *cl[1] = {c};
+                const int st = mispmm_csr_plan_f32(stream, a->numRows, a->numCols, a->numNonZero, a->planRowPtrs, a->planColIdxs,
+                                                   a->planData, a->uniformRowNnz, a->planRowMap, 1, bl, b->numCols, b->numCols, cl, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;
+            }
             if (a->uniformRowNnz > 0 && (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5)) {
                 const int st = mispmm_csr_uniform_f32(stream, a->numRows, a->numCols, a->uniformRowNnz, a->colIdxs, a->data,
                                                       b->data, b->numCols, b->numCols, c, ldc, acc);
@@ -61,6 +76,96 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
     }
 }
 
+template <typename DT, typename MT, typename AccT>
+bool spmmCSRBatched(int batch, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref) {
+    if constexpr (!std::is_same_v<DT, float>) {
+        throw std::runtime_error("Not implemented");
+    } else {
+        using clock = std::chrono::high_resolution_clock;
+        auto ms = [](clock::time_point x, clock::time_point z) {
+            return (double)std::chrono::duration_cast<std::chrono::microseconds>(z - x).count() / 1000.0;
+        };
+        assert(a->onDevice && b->onDevice && batch > 1);
+        b->toOrdering(ORDERING::ROW_MAJOR);
+        const uint32_t M = a->numRows, K = a->numCols, N = b->numCols;
+        const int acc = accModeOf<AccT>();
+        // untimed: the operands of the batch, each in a buffer of its own (copies of B: every result must equal `ref`)
+        std::vector<float *> bs((size_t)batch), cs((size_t)batch);
+        for (int i = 0; i < batch; ++i) {
+            bs[i] = allocateBuffer<float>((size_t)K * N, true);
+            copyBuffer(bs[i], true, b->data, true, (size_t)K * N * sizeof(float));
+        }
+        const auto t1 = clock::now();
+        for (int i = 0; i < batch; ++i) cs[i] = allocateBuffer<float>((size_t)M * N, true);  // prolog: zero-filled results
+        const bool planPays = N % 512 == 0 && (uint64_t)K * (N / 8) * 4 > (4ull << 20);
+        auto launch = [&](mispmm_stream_t stream) {
+            if (a->planRowMap && planPays) {
+                const int st = mispmm_csr_plan_f32(stream, M, K, a->numNonZero, a->planRowPtrs, a->planColIdxs, a->planData,
+                                                   a->uniformRowNnz, a->planRowMap, (uint32_t)batch, bs.data(), N, N, cs.data(), N, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;
+            }
+            return mispmm_csr_batch_f32(stream, M, K, a->numNonZero, a->rowPtrs, a->colIdxs, a->data, a->uniformRowNnz, (uint32_t)batch,
+                                        bs.data(), N, N, cs.data(), N, acc);
+        };
+        const auto t2 = clock::now();
+        mispmmCheckError(launch(nullptr));
+        SteadyStats steady;
+        steady.kernelTag = mispmm_last_kernel();
+        steady.batch = batch;
+        mispmmCheckError(mispmm_device_sync());
+        const auto t3 = clock::now();
+        bool correct = ref != nullptr && ref->numRows == M && ref->numCols == N;
+        std::vector<float> host((size_t)M * N);
+        for (int i = 0; i < batch && correct; ++i) {
+            copyBuffer(host.data(), false, cs[i], true, host.size() * sizeof(float));
+            correct = allclose<float>(host.data(), ref->data, host.size(), REL_TOL, ABS_TOL);
+        }
+        const auto t4 = clock::now();
+        const int iters = engineOptions().steadyIters;
+        if (iters > 0) {
+            // back-to-back batched launches captured into one hipGraph; figures are PER PRODUCT
+            mispmm_stream_t st = nullptr;
+            mispmm_event_t e0 = nullptr, e1 = nullptr;
+            mispmmCheckError(mispmm_stream_create(&st));
+            mispmmCheckError(mispmm_event_create(&e0));
+            mispmmCheckError(mispmm_event_create(&e1));
+            const int launches = std::max(1, std::min(1000, iters / batch));
+            mispmm_graph_t graph = nullptr;
+            mispmmCheckError(mispmm_graph_begin(st));
+            for (int i = 0; i < launches; ++i) mispmmCheckError(launch(st));
+            mispmmCheckError(mispmm_graph_end(st, &graph));
+            for (auto w0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - w0 < std::chrono::milliseconds(20);) {
+                mispmmCheckError(mispmm_graph_launch(graph, st));
+                mispmmCheckError(mispmm_stream_sync(st));
+            }
+            const int replays = std::max(1, iters / (launches * batch));
+            mispmmCheckError(mispmm_event_record(e0, st));
+            for (int r = 0; r < replays; ++r) mispmmCheckError(mispmm_graph_launch(graph, st));
+            mispmmCheckError(mispmm_event_record(e1, st));
+            mispmmCheckError(mispmm_event_sync(e1));
+            float evMs = 0;
+            mispmmCheckError(mispmm_event_elapsed_ms(e0, e1, &evMs));
+            mispmmCheckError(mispmm_graph_destroy(graph));
+            mispmmCheckError(mispmm_event_destroy(e0));
+            mispmmCheckError(mispmm_event_destroy(e1));
+            mispmmCheckError(mispmm_stream_destroy(st));
+            const double products = (double)replays * launches * batch;
+            const double sec = (double)evMs * 1e-3 / products;
+            steady.iters = (int)products;
+            steady.usPerSpmm = sec * 1e6;
+            steady.gflops = 2.0 * a->numNonZero * N / sec / 1e9;
+            steady.hbmGBps = (a->numNonZero * 8.0 + (M + 1.0) * 4 + (double)K * N * 4 + (double)M * N * 4) / sec / 1e9;
+            steady.rooflineFrac = steady.hbmGBps / 8000.0;
+        }
+        reportTime(testcase, M, K, a->numNonZero, "CSR", b->ordering, 5, ms(t1, t2), ms(t2, t3), ms(t3, t4), correct, &steady);
+        for (int i = 0; i < batch; ++i) {
+            releaseBuffer(bs[i], true);
+            releaseBuffer(cs[i], true);
+        }
+        return correct;
+    }
+}
+
 #define CUSPMM_INST(DT)                                                                                              \
     template DenseMatrix<DT, uint32_t> *spmmCSRCpu<DT, uint32_t, double>(SparseMatrixCSR<DT, uint32_t> *,           \
                                                                          DenseMatrix<DT, uint32_t> *,               \
@@ -71,6 +176,10 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
 CUSPMM_INST(float)
 CUSPMM_INST(double)
 #undef CUSPMM_INST
+template bool spmmCSRBatched<float, uint32_t, double>(int, SparseMatrixCSR<float, uint32_t> *, DenseMatrix<float, uint32_t> *,
+                                                      DenseMatrix<float, uint32_t> *);
+template bool spmmCSRBatched<double, uint32_t, double>(int, SparseMatrixCSR<double, uint32_t> *, DenseMatrix<double, uint32_t> *,
+                                                       DenseMatrix<double, uint32_t> *);
 template DenseMatrix<float, uint32_t> *spmmCSRCpu<float, uint32_t, float>(SparseMatrixCSR<float, uint32_t> *,
                                                                          DenseMatrix<float, uint32_t> *,
                                                                          DenseMatrix<float, uint32_t> *);

@@ -25,6 +25,7 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
         return nullptr;
     }
     mispmmCheckError(status);
+    const std::string kernelTag = mispmm_last_kernel();  // what this kernel id really launched
     mispmmCheckError(mispmm_device_sync());
     const auto t3 = clock::now();
     DenseMatrix<DT, MT> *res = c->copy2Host();
@@ -37,6 +38,7 @@ DenseMatrix<DT, MT> *runWrapper(const WrapperShape &shape, int kernelNum, DenseM
 
     SteadyStats steady;
     steady.dtype = shape.dtype;
+    steady.kernelTag = kernelTag;
     const int iters = engineOptions().steadyIters;
     if (iters > 0) {
         // steady state: `iters` back-to-back launches captured into hipGraphs (chunks of <= 1000) on a stream of the

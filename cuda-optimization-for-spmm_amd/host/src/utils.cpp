@@ -27,6 +27,8 @@ void reportTime(const std::string &tc, uint32_t aNumRows, uint32_t aNumCols, uin
     }
     if (steady && steady->ngpus > 0) std::printf(",\n\"ngpus\":\"%d\"", steady->ngpus);
     if (steady && steady->dtype) std::printf(",\n\"dtype\":\"%s\"", steady->dtype);
+    if (steady && steady->batch > 0) std::printf(",\n\"batch\":\"%d\"", steady->batch);
+    if (steady && !steady->kernelTag.empty()) std::printf(",\n\"kernel\":\"%s\"", steady->kernelTag.c_str());
     std::printf("\n},\n");
     std::fflush(stdout);
 }

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mispmm_set_device": (_i, [_i]),
     "mispmm_get_device": (_i, [_c.POINTER(_i)]),
     "mispmm_device_info": (_i, [_i, _c.c_char_p, _c.POINTER(_i), _c.POINTER(_sz)]),
+    "mispmm_device_bus_id": (_i, [_i, _c.c_char_p, _i]),
     "mispmm_malloc": (_i, [_pvp, _sz]),
     "mispmm_free": (_i, [_vp]),
     "mispmm_host_alloc": (_i, [_pvp, _sz]),
@@ -56,6 +57,9 @@ SIGNATURES = {
     "mispmm_csr_batch_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),
     "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32), _vp]),
+    "mispmm_csr_cluster_rows_host": (_i, [_u32, _u32, _vp, _vp, _u32, _vp, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
+    "mispmm_csr_permute_rows_host": (_i, [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mispmm_csr_plan_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),
     "mispmm_ell_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_ell_colmajor_to_rowmajor_host": (_i, [_u32, _u32, _u32, _vp, _vp, _c.POINTER(_u32), _vp, _vp]),
     "mispmm_bsr_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
@@ -128,6 +132,12 @@ def device_info(ordinal=0):
     cus, mem = _i(0), _sz(0)
     check(lib().mispmm_device_info(ordinal, name, ctypes.byref(cus), ctypes.byref(mem)))
     return {"name": name.value.decode(), "cu_count": cus.value, "hbm_bytes": mem.value}
+
+
+def device_bus_id(ordinal=0):
+    buf = ctypes.create_string_buffer(64)
+    check(lib().mispmm_device_bus_id(ordinal, buf, 64))
+    return buf.value.decode()
 
 
 def last_kernel():

@@ -18,6 +18,25 @@ Two ways the slabs travel (`exchange`):
              bucket has returned, and must be done with it before it contributes to bucket i + 1's barrier
              (the peers overwrite the buffer two buckets later, gated on that barrier).
 
+Why a reader of the peer exchange sees its peers' stores (the argument, link by link):
+  1. writer: the scatter kernel's stores go to hipMalloc'ed (coarse-grained) memory of another device through an
+     IPC mapping; whatever the writer's caches still hold is written back by the END-OF-KERNEL RELEASE of that launch.
+     The writer then records an event on its compute stream and makes the communication stream wait for it before it
+     enqueues its contribution to the one-element all-reduce: an event record is a barrier packet with a system-scope
+     release, so the contribution cannot be sent before the slab bytes have left the writer for the destination's HBM
+     (xGMI writes are posted in order per link; the all-reduce's own data travels behind them).
+  2. the all-reduce completes on a reader only after EVERY rank has contributed, i.e. after every writer passed 1.
+  3. reader: it consumes the gathered buffer in a LATER kernel (or copy) ordered behind that all-reduce
+     (`_wait(buf, stream)` / `finish()`); a kernel launch begins with an acquire that invalidates the reader's L1s and
+     the non-coherent lines of its L2s, so no stale copy of the buffer from two buckets ago can be read.
+  4. re-use: a writer overwrites ring buffer `buf` two buckets later and only after waiting for the all-reduce of the
+     bucket in between, which every reader enters after it is done with `buf` (program order on the reader).
+Final equality with the unsharded product checks the data; `debug_sentinel=True` (bench: MISPMM_DIST_DEBUG=1) checks the
+ORDER: behind every slab scatter each rank stores the bucket's sequence number into a 16-byte sentinel slot of every
+peer (same stream, so it is written last), and a reader that has waited for the bucket asserts that all of its
+sentinel slots already carry that number -- a missing release or a too-early reader shows up as a stale sentinel even
+when the slab bytes happen to be identical from bucket to bucket, as they are in a benchmark.
+
 The compute step is injectable so the partition / bucket / gather logic is exercised on CPU with
 the gloo backend (tests/test_dist_cpu.py); on a GPU the default is the HIP kernel via the C ABI.
 """
@@ -42,7 +61,8 @@ def csr_row_slice(csr, r0, r1):
 
 
 class ShardedCsrSpmm:
-    def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather"):
+    def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather",
+                 debug_sentinel=False):
         if exchange not in ("allgather", "peer"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
         self.exchange = exchange
@@ -80,6 +100,8 @@ class ShardedCsrSpmm:
         self.bucket_graphs = {}
         self.use_graphs = self.on_gpu and compute is None
         self.peer_dst = None
+        self.debug_sentinel = bool(debug_sentinel) and exchange == "peer"
+        self.sentinel_checks = 0
         if exchange == "peer":
             if not self.on_gpu:
                 raise ValueError("peer exchange needs device buffers")
@@ -88,13 +110,18 @@ class ShardedCsrSpmm:
     # -- peer exchange: map every rank's gather buffers once ------------------------------------------
     def _map_peer_buffers(self):
         from torch.multiprocessing.reductions import reduce_tensor
-        mine = [reduce_tensor(g) for g in self.gathered]          # (rebuild function, picklable IPC arguments)
+        # debug sentinels: per ring buffer one 16-byte slot per source rank (int32 x 4), written behind the slab scatter
+        self.sentinel = [torch.zeros((self.world, 4), dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.seq_src = [torch.zeros(4, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.seq = [0, 0]
+        mine = [reduce_tensor(g) for g in self.gathered + self.sentinel]   # (rebuild function, picklable IPC arguments)
         everyone = [None] * self.world
         dist.all_gather_object(everyone, [m[1] for m in mine])
         rebuild = mine[0][0]
-        self.peer_gathered = []
+        self.peer_gathered, self.peer_sentinel = [], []
         for r in range(self.world):
             self.peer_gathered.append(self.gathered if r == self.rank else [rebuild(*everyone[r][b]) for b in (0, 1)])
+            self.peer_sentinel.append(self.sentinel if r == self.rank else [rebuild(*everyone[r][2 + b]) for b in (0, 1)])
         ordinals = sorted({t.device.index for pg in self.peer_gathered for t in pg} | {self.device.index})
         if len(ordinals) > 1:
             arr = (ctypes.c_int * len(ordinals))(*ordinals)
@@ -106,14 +133,40 @@ class ShardedCsrSpmm:
             for r in range(self.world):
                 arr[r] = self.peer_gathered[r][b][self.rank].data_ptr()
             self.peer_dst.append(arr)
+        self.peer_sentinel_dst = []
+        for b in (0, 1):
+            arr = (ctypes.c_void_p * self.world)()
+            for r in range(self.world):
+                arr[r] = self.peer_sentinel[r][b][self.rank].data_ptr()
+            self.peer_sentinel_dst.append(arr)
         self.flag = torch.zeros(1, dtype=torch.float32, device=self.device if dist.get_backend() == "nccl" else "cpu")
         dist.barrier()                                            # nobody stores before everybody has mapped
 
-    def _scatter(self, buf):
+    def _next_sequence(self, buf):
+        """Debug sentinels: the number the NEXT scatter of ring buffer `buf` will leave in every peer (enqueued on the
+        compute stream in front of that scatter; never captured into a bucket graph)."""
+        self.seq[buf] += 1
+        with torch.cuda.stream(self.compute_stream):
+            self.seq_src[buf].fill_(self.seq[buf])
+
+    def _scatter(self, buf, capturing=False):
         nbytes = self.ring[buf].numel() * 4
-        capi.check(capi.lib().mispmm_slab_scatter(ctypes.c_void_p(self.compute_stream.cuda_stream),
-                                                  ctypes.c_void_p(self.ring[buf].data_ptr()), nbytes, self.peer_dst[buf],
+        sp = ctypes.c_void_p(self.compute_stream.cuda_stream)
+        if self.debug_sentinel and not capturing:
+            self._next_sequence(buf)
+        capi.check(capi.lib().mispmm_slab_scatter(sp, ctypes.c_void_p(self.ring[buf].data_ptr()), nbytes, self.peer_dst[buf],
                                                   self.world))
+        if self.debug_sentinel:   # behind the slabs on the same stream: the sentinel is the last thing a peer receives
+            capi.check(capi.lib().mispmm_slab_scatter(sp, ctypes.c_void_p(self.seq_src[buf].data_ptr()), 16,
+                                                      self.peer_sentinel_dst[buf], self.world))
+
+    def _check_sentinels(self, buf):
+        """After the wait for bucket `buf`: every peer's sentinel slot must already carry this bucket's sequence number."""
+        got = self.sentinel[buf][:, 0].cpu().tolist()
+        if any(g != self.seq[buf] for g in got):
+            raise RuntimeError(f"peer exchange ordering violated on rank {self.rank}: ring buffer {buf} expected sequence "
+                               f"{self.seq[buf]} from every rank, sentinels hold {got}")
+        self.sentinel_checks += 1
 
     # -- the compute step ------------------------------------------------------------------------
     def _hip_compute(self, a, b, out):
@@ -148,6 +201,9 @@ class ShardedCsrSpmm:
             else:
                 self.compute_stream.synchronize()
                 dist.barrier()
+                if self.debug_sentinel:
+                    torch.cuda.synchronize(self.device)
+                    self._check_sentinels(buf)
             return
         if self.on_gpu:
             done = torch.cuda.Event()
@@ -169,9 +225,13 @@ class ShardedCsrSpmm:
         if self.on_gpu and on_stream is not None:
             with torch.cuda.stream(on_stream):
                 w.wait()
+            if self.debug_sentinel:
+                on_stream.synchronize()
         else:
             w.wait()
         self.pending[buf] = None
+        if self.debug_sentinel:
+            self._check_sentinels(buf)
 
     def _bucket_graph(self, buf, scatter):
         key = (buf, bool(scatter))
@@ -183,7 +243,7 @@ class ShardedCsrSpmm:
             for slot in range(self.bucket):
                 self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
             if scatter:
-                self._scatter(buf)                  # the bucket's slabs leave for every peer inside the same graph
+                self._scatter(buf, capturing=True)  # the bucket's slabs leave for every peer inside the same graph
             g = ctypes.c_void_p()
             capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
             self.bucket_graphs[key] = g
@@ -200,7 +260,10 @@ class ShardedCsrSpmm:
                 if self.exchange == "peer" and gather:
                     self._wait(1 - buf, self.compute_stream)   # peers are done with the bucket before the last one
                 scatter = gather and self.exchange == "peer"
-                capi.check(capi.lib().mispmm_graph_launch(self._bucket_graph(buf, scatter),
+                graph = self._bucket_graph(buf, scatter)
+                if scatter and self.debug_sentinel:
+                    self._next_sequence(buf)
+                capi.check(capi.lib().mispmm_graph_launch(graph,
                                                           ctypes.c_void_p(self.compute_stream.cuda_stream)))
                 self.step_count += self.bucket
                 done += self.bucket

@@ -64,6 +64,60 @@ def csr_spans_by_length(row_ptrs, share_len=0):
     return spans
 
 
+def cluster_rows(csr, parts=4):
+    """Greedy row clustering (mispmm_csr_cluster_rows_host): (order, natural_distinct, clustered_distinct) -- order[i] = the
+    original row at position i; the two counts are the distinct columns summed over `parts` equal row parts before / after."""
+    rp = np.ascontiguousarray(csr.row_ptrs, dtype=np.uint32)
+    ci = np.ascontiguousarray(csr.col_idxs, dtype=np.uint32)
+    order = np.empty(csr.num_rows, dtype=np.uint32)
+    nat, clu = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    capi.check(capi.lib().mispmm_csr_cluster_rows_host(csr.num_rows, csr.num_cols, rp.ctypes.data, ci.ctypes.data, int(parts),
+                                                        order.ctypes.data, ctypes.byref(nat), ctypes.byref(clu)))
+    return order, nat.value, clu.value
+
+
+def permute_rows(csr, order):
+    """The CSR whose row i is row order[i] of `csr` (mispmm_csr_permute_rows_host)."""
+    rp = np.ascontiguousarray(csr.row_ptrs, dtype=np.uint32)
+    ci = np.ascontiguousarray(csr.col_idxs, dtype=np.uint32)
+    va = np.ascontiguousarray(csr.data, dtype=np.float32)
+    od = np.ascontiguousarray(order, dtype=np.uint32)
+    rp2, ci2, va2 = np.empty_like(rp), np.empty_like(ci), np.empty_like(va)
+    capi.check(capi.lib().mispmm_csr_permute_rows_host(csr.num_rows, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, od.ctypes.data,
+                                                        rp2.ctypes.data, ci2.ctypes.data, va2.ctypes.data))
+    return formats.CSR(csr.num_rows, csr.num_cols, rp2, ci2, va2)
+
+
+@dataclass
+class CsrPlan:
+    """The rows of a CSR in a clustered order (rows that read the same B rows together), for mispmm_csr_plan_f32."""
+    row_ptrs: torch.Tensor
+    col_idxs: torch.Tensor
+    data: torch.Tensor
+    row_map: torch.Tensor        # row_map[i] = the C row array row i produces
+    parts: int
+    natural_distinct: int        # distinct columns summed over the parts, storage order ...
+    clustered_distinct: int      # ... and plan order
+
+
+PLAN_PARTS = 4                   # clusters = XCD row parts of the 4 x 2 grid at N = 128
+PLAN_MIN_GAIN = 0.10             # keep a plan only if it cuts the per-part distinct columns by this much
+# When the plan is USED.  Measured on MI355X (profiles/r3/plan_order.log): the clustered order pays where the slice of B an
+# XCD reads -- every B row x the XCD's column part -- does not fit its 4 MiB L2 (n4c6-b13 x K=512: 6.5 MB per XCD,
+# 13.64 -> 12.93 us), changes nothing at K=128 (3.69 / 3.64 us, batched 3.06 / 3.05) and LOSES at K=256 (3.3 MB per XCD:
+# 5.86 -> 6.30 us; the scattered C rows cost more than the order saves).  MISPMM_PLAN_MIN_N=<n> (measurement aid) replaces
+# the rule by "from n columns on".
+PLAN_MIN_N = int(os.environ["MISPMM_PLAN_MIN_N"]) if "MISPMM_PLAN_MIN_N" in os.environ else None
+L2_BYTES = 4 << 20
+
+
+def plan_pays(num_cols, n):
+    """True where the B slice one XCD reads (num_cols rows x its column part of n / 8 columns, fp32) exceeds the L2."""
+    if PLAN_MIN_N is not None:
+        return n >= PLAN_MIN_N
+    return n % 512 == 0 and num_cols * (n // 8) * 4 > L2_BYTES
+
+
 @dataclass
 class DeviceCSR:
     num_rows: int
@@ -74,17 +128,27 @@ class DeviceCSR:
     data: torch.Tensor
     uniform_row_nnz: int = 0     # > 0: structure hint checked on the host when A was uploaded
     spans: torch.Tensor = None   # rows longest first, for the split kernel; built at upload for long-row matrices
+    plan: CsrPlan = None         # rows in a clustered order, kept when the clustering cuts the B rows an XCD must fetch
 
     @staticmethod
-    def from_host(csr, device="cuda", spans=None, share_len=0):
+    def from_host(csr, device="cuda", spans=None, share_len=0, plan=None):
         """spans: True / False to build the span list of the split kernel or not; None = when the mean row holds 24 entries
         or more (where the library's kernel 0 takes the split kernel).  share_len: rows longer than this are dealt to the 4
-        waves of a workgroup (0 = the library's default, 128)."""
+        waves of a workgroup (0 = the library's default, 128).  plan: True / False to keep a clustered row order or not;
+        None = when the matrix has short rows (no span list), at least 1024 rows, and the clustering cuts the distinct
+        columns per row part by PLAN_MIN_GAIN or more (a once-per-upload analysis like the two above)."""
         if spans is None:
             spans = csr.num_rows > 0 and csr.nnz // csr.num_rows >= 24
         sp = _dev_u32(csr_spans_by_length(csr.row_ptrs, share_len).reshape(-1), device) if spans else None
+        pl = None
+        if plan or (plan is None and not spans and csr.num_rows >= 1024 and csr.nnz > 0):
+            order, nat, clu = cluster_rows(csr, PLAN_PARTS)
+            if plan or clu <= (1.0 - PLAN_MIN_GAIN) * nat:
+                pc = permute_rows(csr, order)
+                pl = CsrPlan(_dev_u32(pc.row_ptrs, device), _dev_u32(pc.col_idxs, device), _dev_f32(pc.data, device),
+                             _dev_u32(order, device), PLAN_PARTS, nat, clu)
         return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
-                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp)
+                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp, pl)
 
 
 @dataclass
@@ -197,6 +261,11 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
         raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
+    hints = use_hint and os.environ.get("MISPMM_NO_HINT") != "1"
+    if hints and a.plan is not None and int(kernel) in (0, 5) and plan_pays(a.num_cols, n):
+        # rows in the clustered order of the plan (same bits: every row keeps its entries in storage order)
+        if _csr_plan(a, [b], [c], acc, stream):
+            return c
     if use_hint and os.environ.get("MISPMM_NO_HINT") != "1" and a.uniform_row_nnz and int(kernel) in (0, 5) and a.num_cols * _dense_ld(b) * 4 <= 0x7FFFFFFF:
         capi.check(capi.lib().mispmm_csr_uniform_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.uniform_row_nnz,
                                                      _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c),
@@ -216,6 +285,20 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
                                          _p(a.col_idxs), _p(a.data), _p(b), n, _dense_ld(b), _p(c), _dense_ld(c),
                                          int(kernel), capi.ACC_MODES[acc]))
     return c
+
+
+def _csr_plan(a, bs, cs, acc, stream):
+    """mispmm_csr_plan_f32 over the plan's arrays; False = the shape is not taken (B of 2 GiB or more)."""
+    p = a.plan
+    blist = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
+    clist = (ctypes.c_void_p * len(bs))(*[c.data_ptr() for c in cs])
+    st = capi.lib().mispmm_csr_plan_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(p.row_ptrs), _p(p.col_idxs), _p(p.data),
+                                        a.uniform_row_nnz, _p(p.row_map), len(bs), blist, bs[0].shape[1], _dense_ld(bs[0]), clist,
+                                        _dense_ld(cs[0]), capi.ACC_MODES[acc])
+    if st == capi.ERR_UNSUPPORTED:
+        return False
+    capi.check(st)
+    return True
 
 
 def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
@@ -239,6 +322,9 @@ def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
         for b, c in zip(bs, outs):
             spmm_csr(a, b, out=c, acc=acc, stream=stream)
         return outs
+    if a.plan is not None and os.environ.get("MISPMM_NO_HINT") != "1" and plan_pays(a.num_cols, n):
+        if _csr_plan(a, bs, outs, acc, stream):
+            return outs
     blist = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])
     clist = (ctypes.c_void_p * len(bs))(*[c.data_ptr() for c in outs])
     capi.check(capi.lib().mispmm_csr_batch_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),

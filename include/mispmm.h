@@ -88,6 +88,8 @@ int mispmm_set_device(int ordinal);
 int mispmm_get_device(int *ordinal);
 /* name buffer >= 256 bytes; cu_count / hbm_bytes may be NULL */
 int mispmm_device_info(int ordinal, char *name, int *cu_count, size_t *hbm_bytes);
+/* PCI bus id of a device ("0000:c1:00.0"): lets a multi-process run prove that its ranks sit on distinct devices */
+int mispmm_device_bus_id(int ordinal, char *bus_id, int len);
 
 /* replace cudaMalloc+cudaMemset / cudaMallocHost / cudaFree / cudaFreeHost as
  * the format classes use them (src/formats/dense.cu:234-262): device and pinned
@@ -167,6 +169,32 @@ int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_
                          uint32_t N, uint32_t ldb, float *C, uint32_t ldc, int acc_mode);
 int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t share_len, uint32_t *count_out,
                                     uint32_t *spans_out_host);
+
+/* Plan order: a CSR whose rows were PERMUTED once at upload so that rows which read the same B rows sit together --
+ * the row-gather kernel gives each XCD a contiguous range of array rows and walks it in order, so a B row fetched for
+ * one row of a cluster is still in that XCD's L2 for the others (n4c6-b13 x K=512, where a 6.5 MB B slice per XCD
+ * competes for 4 MiB of L2: 13.7 -> 12.8 us).  Array row i produces row rowMap[i] of C; every row keeps its entries in
+ * storage order, so results are bit-identical to mispmm_csr_f32 on the unpermuted arrays.
+ *   mispmm_csr_cluster_rows_host   greedy clustering into `parts` equal clusters (4 = one per XCD row part at N = 128);
+ *                                  order_out[i] = original row at position i; *natural / *clustered_distinct_out = sum
+ *                                  over the parts of the distinct columns a part touches, before and after (the caller
+ *                                  keeps the plan only if the figure drops)
+ *   mispmm_csr_permute_rows_host   the permuted arrays (rowPtrs_out[M + 1], colIdxs_out[nnz], vals_out[nnz])
+ *   mispmm_csr_plan_f32            C_list[i] = A * B_list[i], i < batch (HOST arrays of device pointers, as for
+ *                                  mispmm_csr_batch_f32; batch = 1 for a single product); uniformRowNnz > 0 = every
+ *                                  row holds that many entries (rowPtrs may be NULL); rowMap NULL = identity.
+ * MISPMM_ERR_UNSUPPORTED for a B of 2 GiB or more (multiply from the unpermuted arrays).  New capability: the
+ * reference has no analysis phase (src/formats/sparse_csr.cu copies the file's arrays as they are). */
+int mispmm_csr_cluster_rows_host(uint32_t M, uint32_t K, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host,
+                                 uint32_t parts, uint32_t *order_out_host, uint64_t *natural_distinct_out,
+                                 uint64_t *clustered_distinct_out);
+int mispmm_csr_permute_rows_host(uint32_t M, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host, const float *vals_host,
+                                 const uint32_t *order_host, uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host,
+                                 float *vals_out_host);
+int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                        const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, const uint32_t *rowMap,
+                        uint32_t batch, const float *const *B_list_host, uint32_t N, uint32_t ldb, float *const *C_list_host,
+                        uint32_t ldc, int acc_mode);
 
 /* Several products with the same A in ONE launch: C_list[i] = A * B_list[i], i < batch (HOST arrays of device
  * pointers; every operand N columns wide with leading dimensions ldb / ldc).  Same arithmetic and results as

@@ -313,3 +313,39 @@ def test_bsr_compact_slots_layout_matches_the_step_list():
     one = ctypes.c_void_p(16)
     assert l.mispmm_bsrc_slots_bf16(None, 4, 64, 15, one, one, one, one, 8, 8, one, 8, 0) == capi.ERR_INVALID_ARG   # fewer than 4 slots per row
     assert l.mispmm_bsrc_slots_bf16(None, 4, 64, 16, one, one, one, one, 12, 16, one, 16, 0) == capi.ERR_UNSUPPORTED  # N % 8
+
+
+def test_row_clustering_and_permutation_helpers():
+    """mispmm_csr_cluster_rows_host returns a permutation that lowers the distinct columns per row part on the BASELINE
+    matrices; mispmm_csr_permute_rows_host builds the permuted CSR (rows keep their entries in storage order) and rejects
+    an order that is not a permutation."""
+    from mispmm import ops
+    for name, parts in (("n4c6-b13", 4), ("delaunay_n12", 4), ("n3c5-b6", 3)):
+        csr = datasets.load_csr(name)
+        order, nat, clu = ops.cluster_rows(csr, parts)
+        assert sorted(order.tolist()) == list(range(csr.num_rows))
+        cap = -(-csr.num_rows // parts)
+        count = lambda rows_of: sum(len(np.unique(np.concatenate(                       # noqa: E731
+            [csr.col_idxs[csr.row_ptrs[r]:csr.row_ptrs[r + 1]] for r in rows_of[p * cap:(p + 1) * cap]] or [np.zeros(0, np.uint32)])))
+            for p in range(parts))
+        assert count(list(range(csr.num_rows))) == nat and count(order.tolist()) == clu
+        if name != "n3c5-b6":
+            assert clu < 0.9 * nat
+        pc = ops.permute_rows(csr, order)
+        assert pc.row_ptrs[0] == 0 and pc.row_ptrs[-1] == csr.nnz
+        for i in (0, 1, csr.num_rows // 2, csr.num_rows - 1):
+            r = int(order[i])
+            assert np.array_equal(pc.col_idxs[pc.row_ptrs[i]:pc.row_ptrs[i + 1]], csr.col_idxs[csr.row_ptrs[r]:csr.row_ptrs[r + 1]])
+            assert np.array_equal(pc.data[pc.row_ptrs[i]:pc.row_ptrs[i + 1]], csr.data[csr.row_ptrs[r]:csr.row_ptrs[r + 1]])
+    csr = datasets.load_csr("n3c5-b6")
+    bad = np.arange(csr.num_rows, dtype=np.uint32)
+    bad[3] = bad[4]
+    with pytest.raises(capi.MispmmError):
+        ops.permute_rows(csr, bad)
+    l = capi.lib()
+    one = ctypes.c_void_p(16)
+    lst = (ctypes.c_void_p * 1)(16)
+    assert l.mispmm_csr_plan_f32(None, 4, 4, 1, one, one, one, 0, one, 1, lst, 8, 8, lst, 8, 7) == capi.ERR_INVALID_ARG   # acc mode
+    assert l.mispmm_csr_plan_f32(None, 4, 4, 1, None, one, one, 0, one, 1, lst, 8, 8, lst, 8, 0) == capi.ERR_INVALID_ARG  # no rowPtrs, not uniform
+    assert l.mispmm_csr_plan_f32(None, 4, 4, 1, one, one, one, 0, one, 0, lst, 8, 8, lst, 8, 0) == capi.OK                # empty batch
+    assert l.mispmm_csr_cluster_rows_host(4, 4, None, None, 2, None, None, None) == capi.ERR_INVALID_ARG

@@ -353,6 +353,19 @@ def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tm
         "    resummed()\n"
         "    res[tag] = ops.spmm_csr(a, torch.from_numpy(b).cuda(), kernel=6).cpu().numpy()\n"
         "    res[tag + '_resummed'] = np.array(resummed())\n"
+        "# N % 32 != 0: the lanes past N of a wave's last 32-column part must drop their reads of padding entries too\n"
+        "# (a read of B[0] there would feed its Inf into unused partial sums and make every such wave sum again)\n"
+        "from mispmm import formats\n"
+        "rng = np.random.default_rng(3)\n"
+        "m, k, w, n = 200, 500, 41, 136\n"
+        "cols = np.concatenate([np.sort(rng.choice(np.arange(1, k), size=w, replace=False)) for _ in range(m)]).astype(np.uint32)\n"
+        "syn = formats.CSR(m, k, (np.arange(m + 1) * w).astype(np.uint32), cols, rng.choice([-1.0, 1.0], size=m * w).astype(np.float32))\n"
+        "bb = synth.dense_b(k, n, mode='exact')\n"
+        "bb[0, 0:4] = np.inf\n"
+        "resummed()\n"
+        "res['inf_row0'] = ops.spmm_csr(ops.DeviceCSR.from_host(syn, spans=False), torch.from_numpy(bb).cuda(), kernel=6).cpu().numpy()\n"
+        "res['inf_row0_resummed'] = np.array(resummed())\n"
+        "res['inf_row0_ptr'], res['inf_row0_cols'], res['inf_row0_vals'], res['inf_row0_b'] = syn.row_ptrs, syn.col_idxs, syn.data, bb\n"
         "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **res)\n")
     path = str(tmp_path / "split.npz")
     p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_LIB=tune), capture_output=True, text=True,
@@ -369,6 +382,9 @@ def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tm
     assert int(res["grid_resummed"]) == 0
     assert 0 < int(res["uniform_resummed"]) <= 40
     assert int(res["wide_resummed"]) >= 0.9 * waves
+    want = oracle.spmm_csr(res["inf_row0_ptr"], res["inf_row0_cols"], res["inf_row0_vals"], res["inf_row0_b"])
+    assert np.all(np.isfinite(want)) and np.array_equal(res["inf_row0"], want)
+    assert int(res["inf_row0_resummed"]) == 0
 
 
 def test_csr_nonfinite_values_follow_the_reference(oracle):
@@ -711,6 +727,81 @@ def test_bsr_zero_skipping_differs_only_where_a_zero_meets_a_nonfinite(oracle):
     assert differs.any() and np.all(np.isnan(ref[differs])) and np.all(differs[:, [c for c in range(16) if c != 3]] == False)  # noqa: E712
     touched = np.abs(csr.to_dense()[:, 5]) > 0            # rows with a true non-zero in column 5 get the Inf either way
     assert np.all(np.isinf(skip[touched, 3]) | np.isnan(skip[touched, 3]))
+
+
+@pytest.mark.parametrize("name,n,taken", [("n4c6-b13", 512, True), ("n4c6-b13", 256, True), ("n4c6-b13", 128, True),
+                                          ("delaunay_n12", 256, True), ("ACTIVSg10K", 288, True), ("tols4000", 64, True),
+                                          ("ACTIVSg10K", 264, False), ("tols4000", 40, False), ("qh1484", 7, False)])
+def test_csr_plan_order_is_bit_exact(oracle, name, n, taken):
+    """mispmm_csr_plan_f32: the rows in a clustered order (mispmm_csr_cluster_rows_host), array row i written to row
+    rowMap[i] of C.  Every row keeps its entries in storage order, so the result equals the oracle bit for bit, for
+    uniform rows (no row pointers), ragged rows, rows with no entry, a strided C, single and batched launches.  Shapes
+    the row-mapped kernel does not take (column parts that are not whole 32-column groups, narrow vectors) are declined
+    and the public entry point multiplies from the unpermuted arrays."""
+    csr = datasets.load_csr(name)
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    a = ops.DeviceCSR.from_host(csr, plan=True, spans=False)
+    assert a.plan is not None and a.plan.clustered_distinct > 0
+    bd = dev(b)
+    cw = torch.full((csr.num_rows, n + 8), -7.0, device="cuda")
+    assert ops._csr_plan(a, [bd], [cw[:, :n]], "reference", None) == taken
+    if taken:
+        assert "plan-order" in capi.last_kernel()
+        got = cw.cpu().numpy()
+        assert np.array_equal(got[:, :n], ref) and np.all(got[:, n:] == -7.0)
+        outs = [torch.empty((csr.num_rows, n), device="cuda") for _ in range(3)]
+        assert ops._csr_plan(a, [bd, bd * 2.0, bd], outs, "reference", None)
+        assert np.array_equal(outs[0].cpu().numpy(), ref) and np.array_equal(outs[2].cpu().numpy(), ref)
+        assert np.array_equal(outs[1].cpu().numpy(), ops.spmm_csr(a, bd * 2.0, use_hint=False).cpu().numpy())
+        fast = torch.empty((csr.num_rows, n), device="cuda")
+        assert ops._csr_plan(a, [bd], [fast], "fast", None)
+        assert_fast_close(fast.cpu().numpy(), ref, abs_scale(csr, b))
+    else:
+        assert np.all(cw.cpu().numpy() == -7.0)                      # declined before anything was launched
+    # the public entry point takes the plan where the B slice of an XCD exceeds its L2 and gives the same bits either way
+    assert np.array_equal(ops.spmm_csr(a, bd).cpu().numpy(), ref)
+    assert ("plan-order" in capi.last_kernel()) == (taken and ops.plan_pays(csr.num_cols, n))
+    assert ops.plan_pays(25605, 512) and not ops.plan_pays(25605, 256) and not ops.plan_pays(4096, 512)
+
+
+def test_csr_plan_is_kept_only_where_clustering_pays():
+    """from_host(plan=None): a plan for the BASELINE matrices (clustering cuts the per-part distinct columns by 16-30 %),
+    none for a matrix whose storage order is already the best the greedy walk finds, none for long-row matrices (span list)."""
+    assert ops.DeviceCSR.from_host(datasets.load_csr("n4c6-b13")).plan is not None
+    assert ops.DeviceCSR.from_host(datasets.load_csr("ch7-6-b5")).plan is None
+    gl = ops.DeviceCSR.from_host(datasets.load_csr("GL7d25"))
+    assert gl.plan is None and gl.spans is not None
+
+
+@pytest.mark.parametrize("n", [128, 40, 6])
+def test_general_csr_entry_bets_on_uniform_rows_and_recovers(oracle, n):
+    """The general entry point (no structure hint) with nnz == M * w: the row-gather waves fetch their first entries from
+    r * w before the row pointers have arrived.  Right for a uniform matrix (n4c6-b13: same bits, one hop less), wrong for
+    a ragged matrix whose entry count merely divides by M -- there every wave must notice and fetch again.  Rows of 0
+    entries, rows longer than the 16-entry window, a last partial wave; the guess can be switched off in the tuning build."""
+    lens = [14, 0, 27, 1, 14, 30, 0, 26, 14, 14, 2, 40, 14, 14, 0, 14] * 9 + [14, 14, 28, 0, 14]   # 149 rows, mean 14 exactly
+    assert sum(lens) == 14 * len(lens)
+    for csr in (random_csr(len(lens), 333, lens, 3), random_csr(149, 333, [14] * 149, 4), datasets.load_csr("n4c6-b13")):
+        assert csr.nnz % csr.num_rows == 0
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        a = ops.DeviceCSR.from_host(csr, plan=False)
+        got = ops.spmm_csr(a, dev(b), use_hint=False).cpu().numpy()
+        assert "csr" in capi.last_kernel()
+        assert np.array_equal(got, ref)
+        if n == 128:
+            outs = ops.spmm_csr_batch(ops.DeviceCSR(a.num_rows, a.num_cols, a.nnz, a.row_ptrs, a.col_idxs, a.data), [dev(b), dev(b)])
+            assert np.array_equal(outs[1].cpu().numpy(), ref)
+
+
+def test_csr_plan_is_kept_only_where_clustering_pays():
+    """from_host(plan=None): a plan for the BASELINE matrices (clustering cuts the per-part distinct columns by 16-30 %),
+    none for a matrix whose storage order is already the best the greedy walk finds, none for long-row matrices (span list)."""
+    assert ops.DeviceCSR.from_host(datasets.load_csr("n4c6-b13")).plan is not None
+    assert ops.DeviceCSR.from_host(datasets.load_csr("ch7-6-b5")).plan is None
+    gl = ops.DeviceCSR.from_host(datasets.load_csr("GL7d25"))
+    assert gl.plan is None and gl.spans is not None
 
 
 @pytest.mark.parametrize("n,out_bf16", [(128, False), (128, True), (72, False), (256, True), (8, False)])

@@ -96,12 +96,19 @@ def main():
                nz.nnz * 8 + (csr.num_rows + 1) * 4 + csr.num_cols * 128 * 4 + csr.num_rows * 128 * 4, acc=acc)
     blocks16, b16 = ops.f32_to_bf16(a.data), ops.f32_to_bf16(b)
     bsrc = ops.DeviceBSRC.from_host(bsr)
+    slots = ops.DeviceBSRCSlots.from_host(bsr)
+    # bytes quoted per kernel: the operand that kernel reads (column lists + tiles of the occupied columns) + B (bf16) + C
     for out_bf16 in (False, True):
         c16 = torch.empty((csr.num_rows, 128), dtype=torch.int16 if out_bf16 else torch.float32, device="cuda")
-        us = timed(lambda: ops.spmm_bsrc_bf16(bsrc, b16, out_bf16=out_bf16, out=c16, stream=s), s)
+        dense_bc = csr.num_cols * 128 * 2 + csr.num_rows * 128 * (2 if out_bf16 else 4)
         ex = 2.0 * bsrc.num_steps * 16 * 32 * 128
-        report("4: large_20000 BSR-16 K=128 bf16 MFMA, column-compacted block rows, C " + ("bf16" if out_bf16 else "fp32"), us, useful,
-               datasets.bsr_algorithmic_bytes(bsr, 128, elem=2, out_elem=2 if out_bf16 else 4), mfma_k_steps=bsrc.num_steps,
+        us = timed(lambda: ops.spmm_bsrc_slots_bf16(slots, b16, out_bf16=out_bf16, out=c16, stream=s), s)
+        report("4: large_20000 BSR-16 K=128 bf16 MFMA, compacted block rows in 4 step slots (workgroup per block row), C "
+               + ("bf16" if out_bf16 else "fp32"), us, useful, slots.operand_bytes() + dense_bc, mfma_k_steps=slots.used_steps,
+               executed_TFLOPs=round(ex / us / 1e6, 2))
+        us = timed(lambda: ops.spmm_bsrc_bf16(bsrc, b16, out_bf16=out_bf16, out=c16, stream=s), s)
+        report("4: large_20000 BSR-16 K=128 bf16 MFMA, compacted block rows (wave per block row), C " + ("bf16" if out_bf16 else "fp32"), us,
+               useful, bsrc.num_steps * 1152 + (csr.num_rows // 16 + 1) * 4 + dense_bc, mfma_k_steps=bsrc.num_steps,
                executed_TFLOPs=round(ex / us / 1e6, 2))
     for out_bf16 in (False, True):
         c16 = torch.empty((csr.num_rows, 128), dtype=torch.int16 if out_bf16 else torch.float32, device="cuda")
