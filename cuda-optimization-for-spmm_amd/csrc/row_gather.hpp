@@ -580,6 +580,9 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
             if (rows.width > 12 && rows.width <= 14) return launch_row_gather_b<G, VEC, Acc, Rows, 128, 8, true, 14>(a, rows, t);
         }
     }
+    // (A kernel specialised on the bet of the general entry point -- CsrRows with exactly nnz / M slots per super-chunk, i.e. the
+    // uniform-row kernel's instruction stream behind the pointer reads -- was built and measured no faster than the ragged
+    // five-body kernel with the bet: 3.73-3.81 vs 3.72-3.77 us on one box, profiles/r3/general_entry.log; not kept.)
     if constexpr (G == 16 && VEC == 4 && std::is_same_v<Rows, CsrRows>) {
         // Long rows: a row's sum is sequential, so its time is (entries / reads in flight) x latency.  Matrices whose
         // MEAN row already fills the 16-slot window (nnz >= 24 M; GL7d25: mean 29, longest 422) take 16 reads in
