@@ -76,12 +76,12 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
         d->rowSpans = uploadRowSpans(this->numRows, this->rowPtrs, 0, count);
         d->numSpans = count;
     } else if constexpr (std::is_same_v<DT, float>) {
-        // short rows: keep a clustered row order when the greedy walk finds one (4 clusters = the XCD row parts of the
-        // 4 x 2 grid at N = 128); the wrapper multiplies from it where the product is bound by what the L2s fetch
+        // short rows: keep a clustered row order when the greedy walk finds one (8 clusters: the best of 4 / 8 / 16 / 64 in the
+        // K = 512 A/B, profiles/r3/plan_order.log); the wrapper multiplies from it where the product is bound by what the L2s fetch
         if (this->numRows >= 1024 && this->numNonZero > 0) {
             std::vector<uint32_t> order(this->numRows);
             uint64_t natural = 0, clustered = 0;
-            mispmmCheckError(mispmm_csr_cluster_rows_host(this->numRows, this->numCols, this->rowPtrs, this->colIdxs, 4, order.data(),
+            mispmmCheckError(mispmm_csr_cluster_rows_host(this->numRows, this->numCols, this->rowPtrs, this->colIdxs, 8, order.data(),
                                                           &natural, &clustered));
             if (clustered * 10 <= natural * 9) {
                 std::vector<uint32_t> ptrs((size_t)this->numRows + 1), cols(this->numNonZero);

@@ -46,8 +46,8 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
         const int acc = accModeOf<AccT>();
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
             // rows in the clustered order copy2Device found, where the slice of B one XCD reads (every B row x its column part
-            // of N / 8 columns) does not fit the 4 MiB L2 -- measured: n4c6-b13 x K=512 13.64 -> 12.93 us, no gain at
-            // K=128, a loss at K=256 (profiles/r3/plan_order.log).  Same bits: every row keeps its entries in storage order.
+            // of N / 8 columns) does not fit the 4 MiB L2 -- measured in one process on one set of operands: n4c6-b13 x K=512 13.60 -> 12.99 us,
+            // K=128 3.47 -> 3.69, K=256 5.75 -> 6.51 (profiles/r3/plan_order.log).  Same bits: every row keeps its entries in storage order.
             const bool planPays = b->numCols % 512 == 0 && (uint64_t)a->numCols * (b->numCols / 8) * 4 > (4ull << 20);
             if (a->planRowMap && planPays && (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5)) {
                 const float *bl[1] = {b->data};

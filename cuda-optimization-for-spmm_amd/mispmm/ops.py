@@ -100,12 +100,12 @@ class CsrPlan:
     clustered_distinct: int      # ... and plan order
 
 
-PLAN_PARTS = 4                   # clusters = XCD row parts of the 4 x 2 grid at N = 128
+PLAN_PARTS = 8                   # clusters: K=512 in-process A/B (profiles/r3/plan_order.log): 4 clusters -3.3 %, 8 -4.5 %, 16 -3.0 %, 64 -0.6 %
 PLAN_MIN_GAIN = 0.10             # keep a plan only if it cuts the per-part distinct columns by this much
-# When the plan is USED.  Measured on MI355X (profiles/r3/plan_order.log): the clustered order pays where the slice of B an
-# XCD reads -- every B row x the XCD's column part -- does not fit its 4 MiB L2 (n4c6-b13 x K=512: 6.5 MB per XCD,
-# 13.64 -> 12.93 us), changes nothing at K=128 (3.69 / 3.64 us, batched 3.06 / 3.05) and LOSES at K=256 (3.3 MB per XCD:
-# 5.86 -> 6.30 us; the scattered C rows cost more than the order saves).  MISPMM_PLAN_MIN_N=<n> (measurement aid) replaces
+# When the plan is USED.  Measured on MI355X, in-process A/B on one set of operands (profiles/r3/plan_order.log): the
+# clustered order pays where the slice of B an XCD reads -- every B row x the XCD's column part -- does not fit its 4 MiB
+# L2 (n4c6-b13 x K=512: 6.5 MB per XCD, 13.60 -> 12.99 us) and LOSES elsewhere (K=128 3.47 -> 3.69 us, K=256 with 3.3 MB
+# per XCD 5.75 -> 6.51: the scattered C rows cost more than the order saves).  MISPMM_PLAN_MIN_N=<n> (measurement aid) replaces
 # the rule by "from n columns on".
 PLAN_MIN_N = int(os.environ["MISPMM_PLAN_MIN_N"]) if "MISPMM_PLAN_MIN_N" in os.environ else None
 L2_BYTES = 4 << 20

@@ -173,9 +173,9 @@ int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, ui
 /* Plan order: a CSR whose rows were PERMUTED once at upload so that rows which read the same B rows sit together --
  * the row-gather kernel gives each XCD a contiguous range of array rows and walks it in order, so a B row fetched for
  * one row of a cluster is still in that XCD's L2 for the others (n4c6-b13 x K=512, where a 6.5 MB B slice per XCD
- * competes for 4 MiB of L2: 13.7 -> 12.8 us).  Array row i produces row rowMap[i] of C; every row keeps its entries in
+ * competes for 4 MiB of L2: 13.6 -> 13.0 us; where the slice fits, the scattered C rows make it a loss: K=128 +6 %).  Array row i produces row rowMap[i] of C; every row keeps its entries in
  * storage order, so results are bit-identical to mispmm_csr_f32 on the unpermuted arrays.
- *   mispmm_csr_cluster_rows_host   greedy clustering into `parts` equal clusters (4 = one per XCD row part at N = 128);
+ *   mispmm_csr_cluster_rows_host   greedy clustering into `parts` equal clusters (the format objects use 8);
  *                                  order_out[i] = original row at position i; *natural / *clustered_distinct_out = sum
  *                                  over the parts of the distinct columns a part touches, before and after (the caller
  *                                  keeps the plan only if the figure drops)
