@@ -337,6 +337,8 @@ extern "C" int mispmm_csr_cluster_rows_host(uint32_t M, uint32_t K, const uint32
                                             uint64_t *clustered_distinct_out) {
     if (!rowPtrs_host || !order_out_host) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: null pointer");
     if (parts == 0) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: parts must be positive");
+    for (uint32_t r = 0; r < M; ++r)
+        if (rowPtrs_host[r + 1] < rowPtrs_host[r]) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: rowPtrs decrease at row %u", r);
     const uint64_t nnz = rowPtrs_host[M];
     if (nnz != 0 && !colIdxs_host) return fail(MISPMM_ERR_INVALID_ARG, "cluster_rows: colIdxs is null");
     for (uint64_t i = 0; i < nnz; ++i)
@@ -420,6 +422,8 @@ extern "C" int mispmm_csr_permute_rows_host(uint32_t M, const uint32_t *rowPtrs_
                                             const uint32_t *order_host, uint32_t *rowPtrs_out_host, uint32_t *colIdxs_out_host,
                                             float *vals_out_host) {
     if (!rowPtrs_host || !order_host || !rowPtrs_out_host) return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: null pointer");
+    for (uint32_t r = 0; r < M; ++r)
+        if (rowPtrs_host[r + 1] < rowPtrs_host[r]) return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: rowPtrs decrease at row %u", r);
     const uint64_t nnz = rowPtrs_host[M];
     if (nnz != 0 && (!colIdxs_host || !vals_host || !colIdxs_out_host || !vals_out_host))
         return fail(MISPMM_ERR_INVALID_ARG, "permute_rows: null entry arrays");
