@@ -82,3 +82,23 @@ def test_row_slice_is_a_standalone_csr():
     assert np.array_equal(part.to_dense(), csr.to_dense()[100:350])
     empty = mdist.csr_row_slice(csr, 7, 7)
     assert empty.num_rows == 0 and empty.nnz == 0
+
+
+def test_bench_parent_stops_every_rank_when_one_dies():
+    """`python bench.py --gpus 2` started plainly spawns its ranks itself and watches all of them: here (no GPU) every
+    rank dies at its first device call, and the parent must come back promptly with a non-zero status and the failing
+    rank's message instead of waiting on rank 0."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (the ranks must fail)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and time.time() - t0 < 60
+    assert "exited with" in p.stderr and "the other ranks were stopped" in p.stderr
+    assert p.stdout.strip() == ""
