@@ -69,7 +69,10 @@ template <> struct BatchArg<true> {
 
 template <int G, int VEC, class Acc, bool CBUF, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
           bool BATCHED = false, bool MAPPED = false>
-__global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : 5) : 1) void row_gather_kernel(
+#ifndef MISPMM_X_WAVES
+#define MISPMM_X_WAVES 5  // experiment builds: another register budget for the 8-reads-in-flight rolling body
+#endif
+__global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) void row_gather_kernel(
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch

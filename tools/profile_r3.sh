@@ -11,7 +11,7 @@ set -u
 OUT=gpurun_out/prof_r3
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
+COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-extras --placements 1"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --gpus 1 $COMMON > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 for f in $(find "$OUT/trace" -name '*kernel_stats.csv'); do cp "$f" "$OUT/bench_kernel_stats.csv"; done
