@@ -234,4 +234,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #endif
 }
 
+// (An experiment kernel with TWO waves per block row -- each taking two of the four step slots with all 16 B-row reads in
+// flight: half the waves to start, one parked tile instead of three, 104 VGPRs -- measured 2.5 % slower, 4.86 against
+// 4.75 us in a same-process A/B, profiles/r3/bsr_waves_ab.log, and was removed again.)
+
 }  // namespace mispmm

@@ -51,7 +51,7 @@ def main():
         got = c.clone()
         if ref is None:
             ref = got
-        assert torch.equal(got, ref), name
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2), name   # variants may add the partial tiles in another (fixed) order
         for k, v in saved.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         assert lib.mispmm_graph_begin(sp) == 0
