@@ -504,7 +504,11 @@ def run_single(args):
                      "algorithmic_bytes_per_launch": w.abytes, "launch_us": round(launch_us, 4),
                      "frac_at_min": round(w.abytes / (stat["min_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "note": "launch_us = HIP-event time of the timed region / launches in it (inter-kernel gaps "
-                             "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src)},
+                             "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src),
+                     "residency": "the steady-state loop multiplies the same A, B into the same C: the working set "
+                                  f"({w.abytes / 1e6:.0f} MB) stays in the 256 MiB Infinity Cache, so `frac` is algorithmic bytes per "
+                                  "second against the 8 TB/s HBM peak (the metric BASELINE.json defines), not measured HBM "
+                                  "traffic; `cold_single_shot` is the same launch after a 1 GiB flush"},
     }
     if w.fmt == "bsr":
         executed = w.executed_flops if w.which == "dense" else 2.0 * w.bsrc.num_steps * 16 * 32 * w.n
