@@ -22,6 +22,10 @@ Where the gathered operand B sits in memory moves the time of one binary on one 
 placement_probe.log: fresh copies of B and C in one process), so the whole measurement above is made on `--placements`
 (default 5) freshly allocated copies of B and C and the line reports the MEDIAN copy; `timing.placements_us` lists them all.
 
+`roofline.traffic` is measured in the same run: before this process touches the GPU it runs the configuration twice as a
+child under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: separate passes, eager launches); profiles/r3/traffic.json is the
+fallback (--no-extras / --no-live-traffic skip the passes).
+
 N > 1.  Started plainly (`python bench.py --gpus N`), this process spawns its N ranks itself (children, before
 it makes any GPU call); under torch.distributed.run it is one of the ranks.  Rows of A are cut into N contiguous
 nnz-balanced ranges, B is broadcast once (outside the timed region), every rank multiplies its slab each step
@@ -87,6 +91,11 @@ def parse():
     p.add_argument("--no-extras", action="store_true",
                    help="skip the other accumulate mode and the cold single shot (profiling passes use this)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="N=1: skip the live PMC measurement.  By default (and unless --no-extras) this configuration is first run "
+                        "twice as a child under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: separate passes, eager launches) "
+                        "before anything here touches the GPU, and roofline.traffic is the L2<->fabric bytes per launch measured "
+                        "there; on any failure the committed figure of profiles/r3/traffic.json is printed instead (adds ~40 s)")
     p.add_argument("--placements", type=int, default=5,
                    help="N=1: time the K steps on this many freshly allocated copies of B and C and report the MEDIAN copy "
                         "(every copy is listed under timing.placements); 1 = the operands as first allocated")
@@ -442,7 +451,67 @@ def load_traffic(key, kernel_tag):
     return entry["total_bytes"], entry.get("source", TRAFFIC_JSON)
 
 
+def live_traffic(args):
+    """L2<->fabric bytes per launch of THIS configuration, measured now: two children of this script under
+    `rocprofv3 --pmc` (one counter group per pass, no trace domains), eager launches, no extras; counters corrected as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and reads half of wide coalesced reads on gfx950; WRITE_SIZE
+    in KiB is exact); first quarter of the dispatches dropped.  Called before this process touches the GPU.  Returns
+    (bytes, kernel_tag, note) or (None, None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, None, "rocprofv3 not on PATH"
+    child = ["python3", os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup", str(args.warmup),
+             "--kernel", str(args.kernel), "--acc", args.acc, "--launch", "eager", "--no-extras", "--no-cpu-baseline", "--placements", "1"]
+    if args.matrix:
+        child += ["--matrix", args.matrix]
+    if args.k_cols:
+        child += ["--k-cols", str(args.k_cols)]
+    means, tag = {}, None
+    tmp = tempfile.mkdtemp(prefix="mispmm_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            proc = subprocess.Popen(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, stdout=subprocess.PIPE,
+                                    stderr=subprocess.PIPE, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", start_new_session=True)
+            try:
+                stdout, stderr = proc.communicate(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)          # exactly the session started above: the profiler and its child
+                proc.communicate()
+                return None, None, f"rocprofv3 --pmc {counter} timed out"
+            if proc.returncode != 0:
+                return None, None, f"rocprofv3 --pmc {counter} failed ({proc.returncode}): {stderr[-300:]}"
+            try:
+                tag = json.loads(stdout.strip().splitlines()[-1])["config"]["kernel_tag"]
+            except Exception:  # noqa: BLE001
+                return None, None, "the profiled child printed no line"
+            per_kernel = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter:
+                            per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not per_kernel:
+                return None, None, f"no {counter} samples in the rocprofv3 output"
+            vals = max(per_kernel.values(), key=len)            # the workload's kernel = the one with the most dispatches
+            vals = vals[len(vals) // 4:]
+            means[counter] = sum(vals) / len(vals)
+    except Exception as e:  # noqa: BLE001  (never let the optional measurement take the line down)
+        return None, None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = int(means["FETCH_SIZE"] * 1024 * 2) + int(means["WRITE_SIZE"] * 1024)
+    return total, tag, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE ({means['FETCH_SIZE']:.1f} KiB x 2 on gfx950) and --pmc WRITE_SIZE "
+                        f"({means['WRITE_SIZE']:.1f} KiB) in separate passes of the same configuration (eager launches, first quarter dropped)")
+
+
 def run_single(args):
+    # children only: nothing in this process has touched the GPU yet
+    live = live_traffic(args) if not (args.no_live_traffic or args.no_extras or args.launch != "graph") else None
     import torch
     from mispmm import capi
     capi.lib()
@@ -478,6 +547,11 @@ def run_single(args):
     achieved = w.abytes / (launch_us * 1e-6) / 1e9
     traffic, traffic_src = load_traffic(f"{args.config}:{w.matrix}/{w.n}/{args.acc}" + ("/nohint" if os.environ.get("MISPMM_NO_HINT") == "1" else ""),
                                         kernel_tag)
+    if live is not None:
+        if live[0] is not None and live[1] == kernel_tag:
+            traffic, traffic_src = live[0], live[2]
+        else:
+            traffic_src = f"{traffic_src} (live measurement unavailable: {live[2] if live[0] is None else 'kernel tag differs'})"
     info = capi.device_info(0)
     out = {
         "metric": metric_label(w),
