@@ -437,7 +437,7 @@ struct XcdTiling {
     bool sc1;
 };
 
-inline XcdTiling xcd_tiling(uint32_t N, int vec) {
+inline XcdTiling xcd_tiling(uint32_t N, int vec, uint32_t K) {
     // environment overrides are read once per process
     struct Env {
         int log2p = -1;
@@ -462,10 +462,13 @@ inline XcdTiling xcd_tiling(uint32_t N, int vec) {
     if (vec >= 2 && N >= 128 && N % 64 == 0) {
         uint32_t q = 2;
         while (q < 8 && N / (q * 2) >= 64 && N % (q * 2 * 32) == 0) q *= 2;  // parts of >= 64 columns, whole 32-column groups
-        // N = 256: eight 32-column parts (every XCD sees all rows, fetches only its own 128-byte slice of each B
-        // row: compulsory fills only) beat 2 x 4 with 64-column parts -- 6.92 vs 7.33 us on n4c6-b13; at N = 128
-        // the same move (2 x 4, 32-column parts) loses, 4.15 vs 4.07 us.
-        if (q == 4 && N == 256) q = 8;
+        // N = 256: with 2 x 4 an XCD reads a 64-column (256-byte) slice of the B rows half of the matrix touches; when
+        // that slice cannot stay in its 4 MiB L2 (K x 256 B > 4 MiB) eight 32-column parts win -- every XCD sees all
+        // rows but fetches only its own 128-byte slice of each B row (compulsory fills only): in-process A/B at
+        // N = 256 (profiles/r3/tiling_ab.log) n4c6-b13 (K = 25 605) 6.16 us against 7.63 for 2 x 4, ACTIVSg10K
+        // (K = 20 000) 12.0 / 12.7; where B is small 2 x 4 is as good or better (delaunay_n12 3.44 / 3.33,
+        // ch7-6-b5 3.61 / 3.56, g7jac010 with K = 2 880: 5.19 / 4.39).  At N = 128 the same move loses (3.55 vs 3.39 us).
+        if (q == 4 && N == 256 && static_cast<uint64_t>(K) * 256u > (4ull << 20)) q = 8;
         t.q = q;
         t.log2p = q == 2 ? 2u : q == 4 ? 1u : 0u;
     }
@@ -606,16 +609,16 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
 
 // Which shapes have a row-mapped (plan order) form: the main rolling body -- 16-byte vectors, column parts of whole
 // 32-column groups, C below 2 GiB (buffer stores), short rows.  mispmm_csr_plan_f32 declines everything else.
-inline bool row_gather_supports_map(uint32_t M, uint32_t N, uint32_t ldc, int vec, uint32_t mean_row_len) {
+inline bool row_gather_supports_map(uint32_t M, uint32_t K, uint32_t N, uint32_t ldc, int vec, uint32_t mean_row_len) {
     if (vec != 4 || static_cast<uint64_t>(M) * ldc * 4u > 0x7FFFFFFFull || mean_row_len >= 24) return false;
-    const XcdTiling t = xcd_tiling(N, vec);
+    const XcdTiling t = xcd_tiling(N, vec, K);
     return t.sc1 && (N / t.q) % 32 == 0;
 }
 
 // needs K * ldb * 4 <= 0x7FFFFFFF (buffer offsets; bit 31 marks dropped loads): callers check
 template <class Acc, class Rows>
 void launch_row_gather_auto(const RowGatherArgs &a, const Rows &rows, int vec) {
-    const XcdTiling t = xcd_tiling(a.N, vec);
+    const XcdTiling t = xcd_tiling(a.N, vec, a.K);
     static const int group_env = knob_int("MISPMM_GROUP", 0);
     // 16 or 8 lanes per row (64 or 32 columns at VEC = 4) whenever they tile the column part exactly: several
     // sub-parts per XCD part (grid.y) instead of one wide, partly idle lane group -- and the rolling body, which

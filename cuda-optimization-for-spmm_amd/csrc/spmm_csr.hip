@@ -706,7 +706,7 @@ extern "C" int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t
     }
     const bool long_rows = uniformRowNnz == 0 && nnz / M >= 24;
     const bool fits = static_cast<uint64_t>(K) * ldb * 4u <= 0x7FFFFFFFull && static_cast<uint64_t>(M) * ldc * 4u <= 0x7FFFFFFFull;
-    const uint32_t cpp = N / xcd_tiling(N, vec).q;
+    const uint32_t cpp = N / xcd_tiling(N, vec, K).q;
     if (vec != 4 || !fits || long_rows || (cpp % 32 != 0)) {  // no batched kernel for this shape: one launch per operand
         for (uint32_t i = 0; i < batch; ++i) {
             const int st = uniformRowNnz ? mispmm_csr_uniform_f32(stream, M, K, uniformRowNnz, colIdxs, vals, B_list_host[i], N, ldb,
@@ -755,10 +755,10 @@ extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t 
     }
     if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull)
         return fail(MISPMM_ERR_UNSUPPORTED, "csr_plan: B of 2 GiB or more: multiply from the unpermuted arrays (mispmm_csr_f32)");
-    if (rowMap && !row_gather_supports_map(M, N, ldc, vec, uniformRowNnz ? uniformRowNnz : nnz / M))
+    if (rowMap && !row_gather_supports_map(M, K, N, ldc, vec, uniformRowNnz ? uniformRowNnz : nnz / M))
         return fail(MISPMM_ERR_UNSUPPORTED, "csr_plan: the row-mapped kernel takes 16-byte-aligned operands with N a multiple of 32 "
                                             "(per XCD column part), C below 2 GiB and short rows: multiply from the unpermuted arrays");
-    const bool batched_ok = vec == 4 && static_cast<uint64_t>(M) * ldc * 4u <= 0x7FFFFFFFull && (N / xcd_tiling(N, vec).q) % 32 == 0 &&
+    const bool batched_ok = vec == 4 && static_cast<uint64_t>(M) * ldc * 4u <= 0x7FFFFFFFull && (N / xcd_tiling(N, vec, K).q) % 32 == 0 &&
                             !(uniformRowNnz == 0 && nnz / M >= 24);
     auto launch = [&](RowGatherArgs &ga) {
         ga.rowMap = rowMap;

@@ -1,5 +1,5 @@
 """A/B of library builds on config 4 (ACTIVSg10K BSR-16 x K=128 bf16, the slots kernel) in ONE process on ONE set of operands.
-  python tools/probe/bsr_ab_probe.py name=path[:VAR=val,...] ...          GPU box only."""
+  python tools/probe/bsr_ab_probe.py name=path[:VAR=val;VAR=val...] ...          GPU box only."""
 import ctypes
 import os
 import shutil
@@ -30,7 +30,7 @@ def main():
     for i, spec in enumerate(sys.argv[1:]):
         name, rest = spec.split("=", 1)
         path, _, envs = rest.partition(":")
-        env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+        env = dict(kv.split("=", 1) for kv in envs.split(";") if kv)
         copy = os.path.join(tmp, f"lib_{i}.so")
         shutil.copy(os.path.join(ROOT, path), copy)
         saved = {k: os.environ.get(k) for k in env}

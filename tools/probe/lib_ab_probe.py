@@ -1,7 +1,7 @@
 """A/B of library builds / measurement knobs in ONE process on the SAME operands (operand placement moves the headline by up
 to 6 % from process to process, profiles/r3/placement_probe.log -- small effects need this).
 
-  python tools/probe/lib_ab_probe.py [--entry uniform|general] [--k-cols 128] name=path[:VAR=val,...] ...
+  python tools/probe/lib_ab_probe.py [--entry uniform|general] [--k-cols 128] name=path[:VAR=val;VAR=val...] ...
 Each variant is a copy of the named library loaded under its own name (so its `static const` knobs are read with ITS
 environment); every variant multiplies the same A, B into the same C through a 1000-launch graph; rounds are interleaved.
 GPU box only."""
@@ -59,7 +59,7 @@ def main():
     for i, spec in enumerate(a.variants):
         name, rest = spec.split("=", 1)
         path, _, envs = rest.partition(":")
-        env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+        env = dict(kv.split("=", 1) for kv in envs.split(";") if kv)
         lib, saved = load(os.path.join(ROOT, path) if not os.path.isabs(path) else path, env, tmp, f"{i}")
 
         def call(lib=lib):
