@@ -40,7 +40,18 @@ static __device__ unsigned long long *mispmm_bsr_stamp_buf = nullptr;
 //   * waves 1..3 park their tile in LDS (24 KiB per workgroup), wave 0 keeps its own in registers and adds the three
 //     parked tiles in wave order; extra steps (block rows of more than 4 steps) go to waves 1..3 only, which add them
 //     into their parked tile -- a lane re-reads exactly the words it wrote, so that needs no barrier.
-template <bool C_BF16, int ST>
+//
+// SHARE (every block row has <= 4 steps, i.e. no extra steps -- config 4): the reduce and the store are dealt over the
+// four waves as well.  Wave q owns rows 4q .. 4q+3 of the block row: every wave parks the three row quads it does not
+// own (the lanes of the other three lane groups; 6 KiB per wave, the same 24 KiB per workgroup), and after the barrier
+// the 16 lanes of lane group q of wave q add the quads the other USED slots parked to their own, in wave order, and
+// store 4 rows.  With wave 0 doing all of it the block row's result waited for 24 LDS reads + 8 stores of one wave
+// behind the barrier (stamps: 0.84 us p90 from barrier to the last store issued); dealt out it is a quarter of that
+// per wave: 4.73 -> 4.50 us on config 4 in a same-process A/B (profiles/r3/bsr_share_ab.log).  Tried on top of it and not
+// kept: the A tile read issued before the column list returns (+0.2 %), the LDS reads of two rows in flight at once
+// (more registers, a resident workgroup less per CU: +73 %).  The stamps of this version show the kernel in two phases,
+// reads until ~2.0 us (the barrier), then 10 MB of C stores from every workgroup at once.
+template <bool C_BF16, int ST, bool SHARE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void bsrc_slots_mfma_bf16(uint32_t Mb, uint32_t nST, const uint32_t *__restrict__ extraPtrs,
                                                             const uint32_t *__restrict__ cols, const uint16_t *__restrict__ tiles,
                                                             const uint16_t *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
@@ -56,6 +67,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // [wave - 1][row of the block row][128 columns]: 24 KiB.  No padding needed: a ds_write_b128 is served in groups of
     // 8 consecutive lanes = 256 contiguous bytes here, and so is the read back.
     __shared__ float parked[kBsrSlots - 1][16][128];
+    static_assert(sizeof(parked) == kBsrSlots * (kBsrSlots - 1) * 4 * 128 * sizeof(float), "SHARE views the same 24 KiB as [wave][quad slot][4][128]");
 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
@@ -142,7 +154,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 #endif
         }
     };
-    if (wave != 0) {
+    // one row of the result: this lane's 8 columns
+    auto store_row = [&](uint32_t row, const f32x4_t &s0, const f32x4_t &s1) {
+        const size_t crow = static_cast<size_t>(row) * ldc + ncol;
+        if constexpr (C_BF16) {
+            using bf2 = __bf16 __attribute__((ext_vector_type(2)));
+            u32x4_t o;
+            o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[0]), static_cast<__bf16>(s0[1])});
+            o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[2]), static_cast<__bf16>(s0[3])});
+            o[2] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[0]), static_cast<__bf16>(s1[1])});
+            o[3] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[2]), static_cast<__bf16>(s1[3])});
+            if constexpr (ST >= 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(o, make_rsrc(Cv, c_bytes), static_cast<uint32_t>(crow * 2u), 0, ST);
+            } else {
+                *reinterpret_cast<u32x4_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
+            }
+        } else {
+            if constexpr (ST >= 0) {
+                const rsrc_t crs = make_rsrc(Cv, c_bytes);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), crs, static_cast<uint32_t>(crow * 4u), 0, ST);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s1), crs, static_cast<uint32_t>(crow * 4u + 16u), 0, ST);
+            } else {
+                float *dst = static_cast<float *>(Cv) + crow;
+                *reinterpret_cast<f32x4_t *>(dst) = s0;
+                *reinterpret_cast<f32x4_t *>(dst + 4) = s1;
+            }
+        }
+    };
+    if constexpr (SHARE) {
+        f32x4_t t[TPL];
+        slot_tile(t);  // zeros for an unused slot: parked like any other, so the adds below need no case distinction
+        float *quads = &parked[0][0][0];  // [wave][quad slot 0..2][row of the quad][128 columns]
+        if (g != wave) {
+            // lane (c, g) holds rows 4g .. 4g+3 = quad g, which wave g owns; quad slot = g with this wave's own quad left out
+            float *dst = quads + ((wave * (kBsrSlots - 1) + (g - (g > wave ? 1u : 0u))) * 4u) * 128u + c * 8u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                *reinterpret_cast<f32x4_t *>(dst + r * 128) = f32x4_t{t[0][r], t[1][r], t[2][r], t[3][r]};
+                *reinterpret_cast<f32x4_t *>(dst + r * 128 + 4) = f32x4_t{t[4][r], t[5][r], t[6][r], t[7][r]};
+            }
+        }
+        MISPMM_BSR_STAMP(3);
+        __syncthreads();
+        MISPMM_BSR_STAMP(4);
+        // one straight-line body per owner wave (the position of the wave's own tile in the sum is then a constant: every
+        // LDS read of a row is issued before the first add; with the wave index as data hipcc serialised them behind branches)
+        auto reduce_quad = [&](auto owner) {
+            constexpr uint32_t Q = decltype(owner)::value;
+            if (g != Q || ncol >= N) return;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x4_t p0[kBsrSlots], p1[kBsrSlots];
+#pragma unroll
+                for (uint32_t w = 0; w < kBsrSlots; ++w) {
+                    if (w == Q) {
+                        p0[w] = f32x4_t{t[0][r], t[1][r], t[2][r], t[3][r]};
+                        p1[w] = f32x4_t{t[4][r], t[5][r], t[6][r], t[7][r]};
+                    } else {
+                        const float *src = quads + ((w * (kBsrSlots - 1) + (Q - (Q > w ? 1u : 0u))) * 4u + r) * 128u + c * 8u;
+                        p0[w] = *reinterpret_cast<const f32x4_t *>(src);
+                        p1[w] = *reinterpret_cast<const f32x4_t *>(src + 4);
+                    }
+                }
+                // wave order = ascending step order, as the kernel without SHARE adds them
+                store_row(R * 16 + Q * 4 + r, ((p0[0] + p0[1]) + p0[2]) + p0[3], ((p1[0] + p1[1]) + p1[2]) + p1[3]);
+            }
+        };
+        if (wave == 0) reduce_quad(std::integral_constant<uint32_t, 0>{});
+        else if (wave == 1) reduce_quad(std::integral_constant<uint32_t, 1>{});
+        else if (wave == 2) reduce_quad(std::integral_constant<uint32_t, 2>{});
+        else reduce_quad(std::integral_constant<uint32_t, 3>{});
+    } else if (wave != 0) {
         {
             f32x4_t t[TPL];
             slot_tile(t);
@@ -193,30 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     s0 += *reinterpret_cast<const f32x4_t *>(&parked[p][g * 4 + r][c * 8]);
                     s1 += *reinterpret_cast<const f32x4_t *>(&parked[p][g * 4 + r][c * 8 + 4]);
                 }
-                const size_t crow = static_cast<size_t>(R * 16 + g * 4 + r) * ldc + ncol;
-                if constexpr (C_BF16) {
-                    using bf2 = __bf16 __attribute__((ext_vector_type(2)));
-                    u32x4_t o;
-                    o[0] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[0]), static_cast<__bf16>(s0[1])});
-                    o[1] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s0[2]), static_cast<__bf16>(s0[3])});
-                    o[2] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[0]), static_cast<__bf16>(s1[1])});
-                    o[3] = __builtin_bit_cast(uint32_t, bf2{static_cast<__bf16>(s1[2]), static_cast<__bf16>(s1[3])});
-                    if constexpr (ST >= 0) {
-                        __builtin_amdgcn_raw_buffer_store_b128(o, make_rsrc(Cv, c_bytes), static_cast<uint32_t>(crow * 2u), 0, ST);
-                    } else {
-                        *reinterpret_cast<u32x4_t *>(static_cast<uint16_t *>(Cv) + crow) = o;
-                    }
-                } else {
-                    if constexpr (ST >= 0) {
-                        const rsrc_t crs = make_rsrc(Cv, c_bytes);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s0), crs, static_cast<uint32_t>(crow * 4u), 0, ST);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, s1), crs, static_cast<uint32_t>(crow * 4u + 16u), 0, ST);
-                    } else {
-                        float *dst = static_cast<float *>(Cv) + crow;
-                        *reinterpret_cast<f32x4_t *>(dst) = s0;
-                        *reinterpret_cast<f32x4_t *>(dst + 4) = s1;
-                    }
-                }
+                store_row(R * 16 + g * 4 + r, s0, s1);
             }
         }
     }

@@ -910,18 +910,27 @@ extern "C" int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockR
     // (measurement aid; buffer stores need C below 2 GiB, else plain)
     static const int store_knob = knob_int("MISPMM_BSR_STORE", 2);
     const int st = c_bytes <= 0x7FFFFFFFull ? store_knob : -1;
-    note_kernel("bsrc_slots_mfma_bf16<%s,%s>", c_bf16 ? "c16" : "c32", st == 2 ? "nt" : st == 16 ? "sc1" : st == 18 ? "sc1nt" : "plain");
-#define MISPMM_SLOTS_LAUNCH(CB, ST)                                                                                            \
-    hipLaunchKernelGGL((bsrc_slots_mfma_bf16<CB, ST>), dim3(xg.grid), dim3(256), 0, as_stream(stream), numBlockRows, nST, extraPtrs, \
+    // no extra steps (every block row has at most 4): the kernel that deals the reduce and the store over the four waves
+    // (MISPMM_BSR_SHARE=0 keeps wave 0 doing both: measurement aid)
+    static const int share_knob = knob_int("MISPMM_BSR_SHARE", 1);
+    const bool share = share_knob != 0 && nSteps == numBlockRows * kBsrSlots;
+    note_kernel("bsrc_slots_mfma_bf16<%s,%s%s>", c_bf16 ? "c16" : "c32", st == 2 ? "nt" : st == 16 ? "sc1" : st == 18 ? "sc1nt" : "plain",
+                share ? ",share" : "");
+#define MISPMM_SLOTS_LAUNCH(CB, ST, SH)                                                                                            \
+    hipLaunchKernelGGL((bsrc_slots_mfma_bf16<CB, ST, SH>), dim3(xg.grid), dim3(256), 0, as_stream(stream), numBlockRows, nST, extraPtrs, \
                        cols, tiles, B, b_bytes, N, ldb, C, static_cast<uint32_t>(st >= 0 ? c_bytes : 0), ldc, xg.chunk)
-#define MISPMM_SLOTS_PICK(CB)                        \
-    do {                                             \
-        if (st == 2) MISPMM_SLOTS_LAUNCH(CB, 2);     \
-        else if (st == 16) MISPMM_SLOTS_LAUNCH(CB, 16); \
-        else if (st == 18) MISPMM_SLOTS_LAUNCH(CB, 18); \
-        else MISPMM_SLOTS_LAUNCH(CB, -1);            \
+#define MISPMM_SLOTS_PICK(CB, SH)                        \
+    do {                                                 \
+        if (st == 2) MISPMM_SLOTS_LAUNCH(CB, 2, SH);     \
+        else if (st == 16) MISPMM_SLOTS_LAUNCH(CB, 16, SH); \
+        else if (st == 18) MISPMM_SLOTS_LAUNCH(CB, 18, SH); \
+        else MISPMM_SLOTS_LAUNCH(CB, -1, SH);            \
     } while (0)
-    if (c_bf16) MISPMM_SLOTS_PICK(true); else MISPMM_SLOTS_PICK(false);
+    if (share) {
+        if (c_bf16) MISPMM_SLOTS_PICK(true, true); else MISPMM_SLOTS_PICK(false, true);
+    } else {
+        if (c_bf16) MISPMM_SLOTS_PICK(true, false); else MISPMM_SLOTS_PICK(false, false);
+    }
 #undef MISPMM_SLOTS_PICK
 #undef MISPMM_SLOTS_LAUNCH
     MISPMM_LAUNCH_CHECK();

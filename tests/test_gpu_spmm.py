@@ -925,6 +925,42 @@ def test_bsrc_slots_bf16_ragged_rows_extra_steps_and_strides(oracle):
         ops.spmm_bsrc_slots_bf16(a, ops.f32_to_bf16(dev(synth.dense_b(kb * bc, 12))))
 
 
+def test_bsrc_slots_shared_reduce_returns_the_bits_of_the_wave0_reduce():
+    """Block rows of at most 4 steps (no extra steps: config 4) take the kernel instance that deals the reduce and the
+    store over the four waves; it adds the partial tiles in the same wave order as the instance in which wave 0 does both
+    (what every layout with extra steps runs), so the two must agree bit for bit.  MISPMM_BSR_SHARE=0 (tuning build, read
+    once per process: child process) forces the latter."""
+    import subprocess
+    import sys
+    import tempfile
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cuda-optimization-for-spmm_amd")
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {pkg!r})\n"
+        "from mispmm import capi, datasets, formats, ops, synth\n"
+        "csr = datasets.load_csr('ACTIVSg10K'); a = ops.DeviceBSRCSlots.from_host(formats.csr_to_bsr(csr, 16))\n"
+        "out = {}\n"
+        "for n in (128, 72, 256):\n"
+        "    b = ops.f32_to_bf16(torch.from_numpy(synth.dense_b(csr.num_cols, n)).cuda())\n"
+        "    for c16 in (0, 1):\n"
+        "        out['%d_%d' % (n, c16)] = ops.spmm_bsrc_slots_bf16(a, b, out_bf16=bool(c16)).cpu().numpy()\n"
+        "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **out)\n")
+    tune = os.path.join(pkg, "libmispmm_tune.so")
+    assert os.path.exists(tune), "run `make -C cuda-optimization-for-spmm_amd tune`"
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for share in ("0", "1"):
+            path = os.path.join(tmp, f"out{share}.npz")
+            p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_BSR_SHARE=share, MISPMM_LIB=tune),
+                               capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-2000:]
+            res[share] = dict(np.load(path))
+        assert "share" in str(res["1"]["tag"]) and "share" not in str(res["0"]["tag"])
+        for key in res["0"]:
+            if key != "tag":
+                assert np.array_equal(res["0"][key].view(np.uint8), res["1"][key].view(np.uint8)), key
+
+
 def bsr_to_dense(bsr, data):
     d = np.zeros((bsr.num_rows, bsr.num_cols), dtype=np.float32)
     br, bc = bsr.block_row_size, bsr.block_col_size
