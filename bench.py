@@ -88,6 +88,8 @@ def parse():
                    help="N>1: how C slabs travel: `allgather` = RCCL all_gather_into_tensor, `peer` = direct stores into "
                         "IPC-mapped peer buffers, `both` (default) measures the two and reports the faster as `value`")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--mode-timeout", type=int, default=240,
+                   help="N>1: seconds an exchange mode after the first measured one may take before the line is printed without it (0 = wait)")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the other accumulate mode and the cold single shot (profiling passes use this)")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget")
@@ -704,68 +706,6 @@ def run_multi(args):
     abytes = datasets.csr_algorithmic_bytes(csr, n)
     results, whole, gathered_host = {}, None, None
     shard_bounds = mdist.shard_bounds(csr.row_ptrs, world)
-    for mode in modes:
-        try:
-            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode,
-                                       debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
-        except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
-            results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
-            job = None
-        # every rank must agree on whether the mode is usable
-        flag = torch.tensor([1.0 if job is not None else 0.0], device="cpu" if shared_gpu else device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if float(flag[0]) == 0.0:
-            if job is not None:
-                job.close()
-                results[mode] = {"unavailable": "another rank could not set the exchange up"}
-            continue
-        job.broadcast_b(b_host)                      # one-time, outside the timed region
-        job.run(args.warmup)
-        job.finish()
-
-        def timed(total_steps, gather):
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            job.run(total_steps, gather=gather)
-            job.finish(gather=gather)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared_gpu else device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank uses the same (slowest) figure
-            return float(t[0])
-
-        # as at N = 1: the K steps are repeated until the timed region lasts >= 20 ms (a single pass of a small K times
-        # the launch latency of one bucket graph and one collective, not a step); `replays` says how often
-        est = timed(args.steps, True)
-        replays = max(1, int(np.ceil(TIMED_S / max(est, 1e-6))))
-        unit = bucket // int(np.gcd(args.steps, bucket))       # replays that make K * R a whole number of buckets
-        replays = -(-replays // unit) * unit
-        wall = timed(args.steps * replays, True) / replays
-        # the same steps with C left row-sharded (no exchange): the kernel-only figure
-        compute_s = timed(args.steps * replays, False) / replays
-        # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
-        job.run(1)
-        job.finish()
-        from mispmm import ops
-        if whole is None:
-            whole = ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=device), job.b, kernel=args.kernel, acc=args.acc)
-            torch.cuda.synchronize()
-        ok = torch.tensor([1.0 if torch.equal(whole, job.gathered_c()) else 0.0], device="cpu" if shared_gpu else device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok[0]) == 0.0:
-            raise SystemExit(f"bench: exchanged C ({mode}) differs from the unsharded product -- refusing to report a number")
-        if rank == 0:
-            gathered_host = job.gathered_c().cpu().numpy()
-        results[mode] = {"replays": replays,
-                         "value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
-                         "kernel_only_value": round(flops * args.steps / compute_s / 1e9, 2),
-                         "kernel_only_ms_per_step": round(compute_s * 1e3 / args.steps, 6)}
-        if job.debug_sentinel:
-            # MISPMM_DIST_DEBUG=1: every wait for a bucket checked that all peers' sentinels (written behind their slabs)
-            # had already arrived -- the timing of such a run is not a measurement (host syncs per bucket)
-            results[mode]["sentinel_checks"] = job.sentinel_checks
-        job.close()
     # who took part: every rank reports its device (PCI bus id) and the algorithmic bytes of ITS shard -- its slice of A,
     # the B rows its columns touch, its C slab ("multi-GPU per device ... node total = sum")
     r0, r1 = int(shard_bounds[rank]), int(shard_bounds[rank + 1])
@@ -776,7 +716,8 @@ def run_multi(args):
             "algorithmic_bytes": (e1 - e0) * 8 + (r1 - r0 + 1) * 4 + touched * n * 4 + (r1 - r0) * n * 4}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
-    if rank == 0:
+    def compose_and_emit():
+        """rank 0: the contract line from the exchange modes measured so far"""
         usable = {m: r for m, r in results.items() if "value" in r}
         if not usable:
             raise SystemExit(f"bench: no exchange mode could run: {results}")
@@ -823,6 +764,107 @@ def run_multi(args):
             shim.workload = out["config"]["workload"]
             out["cpu_baseline"] = cpu_baseline(shim, args.cpu_seconds, gathered_host, args.acc)
         emit(out)
+
+    def run_mode(mode):
+        nonlocal whole, gathered_host
+        if os.environ.get("MISPMM_BENCH_STALL") == mode:   # test hook: this mode never finishes (tests/test_gpu_multi.py)
+            time.sleep(3600)
+        try:
+            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode,
+                                       debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
+        except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
+            results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
+            job = None
+        # every rank must agree on whether the mode is usable
+        flag = torch.tensor([1.0 if job is not None else 0.0], device="cpu" if shared_gpu else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) == 0.0:
+            if job is not None:
+                job.close()
+                results[mode] = {"unavailable": "another rank could not set the exchange up"}
+            return
+        job.broadcast_b(b_host)                      # one-time, outside the timed region
+        job.run(args.warmup)
+        job.finish()
+
+        def timed(total_steps, gather):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.run(total_steps, gather=gather)
+            job.finish(gather=gather)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # every rank uses the same (slowest) figure
+            return float(t[0])
+
+        # as at N = 1: the K steps are repeated until the timed region lasts >= 20 ms (a single pass of a small K times
+        # the launch latency of one bucket graph and one collective, not a step); `replays` says how often
+        est = timed(args.steps, True)
+        replays = max(1, int(np.ceil(TIMED_S / max(est, 1e-6))))
+        unit = bucket // int(np.gcd(args.steps, bucket))       # replays that make K * R a whole number of buckets
+        replays = -(-replays // unit) * unit
+        wall = timed(args.steps * replays, True) / replays
+        # the same steps with C left row-sharded (no exchange): the kernel-only figure
+        compute_s = timed(args.steps * replays, False) / replays
+        # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
+        job.run(1)
+        job.finish()
+        from mispmm import ops
+        if whole is None:
+            whole = ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=device), job.b, kernel=args.kernel, acc=args.acc)
+            torch.cuda.synchronize()
+        ok = torch.tensor([1.0 if torch.equal(whole, job.gathered_c()) else 0.0], device="cpu" if shared_gpu else device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok[0]) == 0.0:
+            # no number for an exchange that delivered wrong bytes; the other modes are still measured and the line says so
+            results[mode] = {"failed": "exchanged C differs from the unsharded single-GPU product on at least one rank"}
+            job.close()
+            return
+        if rank == 0:
+            gathered_host = job.gathered_c().cpu().numpy()
+        results[mode] = {"replays": replays,
+                         "value": round(flops * args.steps / wall / 1e9, 2), "ms_per_step": round(wall * 1e3 / args.steps, 6),
+                         "kernel_only_value": round(flops * args.steps / compute_s / 1e9, 2),
+                         "kernel_only_ms_per_step": round(compute_s * 1e3 / args.steps, 6)}
+        if job.debug_sentinel:
+            # MISPMM_DIST_DEBUG=1: every wait for a bucket checked that all peers' sentinels (written behind their slabs)
+            # had already arrived -- the timing of such a run is not a measurement (host syncs per bucket)
+            results[mode]["sentinel_checks"] = job.sentinel_checks
+        job.close()
+
+    def start_watchdog(mode):
+        """A later exchange mode that does not finish (it has only ever run between processes on one card) must not cost
+        the line the earlier modes earned: after --mode-timeout seconds rank 0 prints the line with what was measured
+        and every rank leaves."""
+        import threading
+
+        def expire():
+            results[mode] = {"unavailable": f"did not finish within {args.mode_timeout} s (watchdog); the line reports the modes before it"}
+            if rank == 0:
+                try:
+                    compose_and_emit()
+                    sys.stdout.flush()
+                finally:
+                    os._exit(0)
+            time.sleep(30)                     # rank 0 prints first
+            os._exit(0)
+
+        t = threading.Timer(args.mode_timeout, expire)
+        t.daemon = True
+        t.start()
+        return t
+
+    for mode in modes:
+        watchdog = start_watchdog(mode) if args.mode_timeout > 0 and any("value" in r for r in results.values()) else None
+        try:
+            run_mode(mode)
+        finally:
+            if watchdog is not None:
+                watchdog.cancel()
+    if rank == 0:
+        compose_and_emit()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -189,6 +189,17 @@ def test_distributed_line_with_one_rank_agrees_with_the_plain_line():
     assert 0.92 * lo <= b <= 1.08 * hi, (plain["timing"]["placements_us"], b)
 
 
+def test_a_stuck_exchange_mode_does_not_cost_the_line():
+    """`--exchange both` measures the RCCL all-gather first and the peer stores second.  The peer exchange has only ever
+    run between processes on one card; should it hang on a real 8-GPU node, the watchdog prints the line with the modes
+    measured before it and ends every rank with exit code 0.  MISPMM_BENCH_STALL=peer makes the mode sleep forever."""
+    line = _bench("--gpus", "2", "--steps", "16", "--warmup", "4", "--bucket", "8", "--cpu-seconds", "1", "--mode-timeout", "5",
+                  env={"MISPMM_SHARE_GPU": "1", "MISPMM_BENCH_STALL": "peer"})
+    assert line["n_gpus"] == 2 and "value" in line["exchange_modes"]["allgather"]
+    assert "watchdog" in line["exchange_modes"]["peer"]["unavailable"]
+    assert line["value"] == line["exchange_modes"]["allgather"]["value"] and line["cpu_baseline"]["gpu_parity"] == "bit-exact"
+
+
 def test_peer_exchange_between_two_processes_on_one_card():
     """Two ranks share the card (gloo carries the control messages, IPC handles map each rank's gather buffers into
     the other): `bench.py --gpus 2` spawns its ranks itself and refuses to print unless the exchanged C equals the
