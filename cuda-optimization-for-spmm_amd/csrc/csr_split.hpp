@@ -86,12 +86,14 @@ inline SplitTiling split_tiling(uint32_t M, uint32_t N, uint32_t waves, bool spa
     return t;
 }
 
+// the kernel's body; (bx, by) = the workgroup's position in a grid of its own (csr_hybrid runs it on the first workgroups
+// of a launch whose other workgroups take the short rows through the row-gather body)
 template <class Acc, int WAVES, int NB>
-__global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32_t *__restrict__ rowPtrs,
-                                                        const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
-                                                        const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
-                                                        float *__restrict__ C, uint32_t ldc, uint32_t tile_q,
-                                                        uint32_t rows_per_part, const uint32_t *__restrict__ spans) {
+__device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t by, uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                               const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                               const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                               float *__restrict__ C, uint32_t ldc, uint32_t tile_q, uint32_t rows_per_part,
+                                               const uint32_t *__restrict__ spans) {
     using u2 = uint32_t __attribute__((ext_vector_type(2)));
     using T = typename Acc::T;
     constexpr bool kRef = std::is_same_v<Acc, AccRefWide>;
@@ -117,16 +119,16 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
     const uint32_t lane = threadIdx.x & 63u;
     // workgroups are dealt round-robin over the XCDs: blockIdx.x & 7 is the XCD, which owns one (row part, column part).
     // Placement only: any dispatch order gives the same result.
-    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t xcd = bx & 7u;   // (blockIdx.x of the split grid)
     const uint32_t part_row = xcd / tile_q, part_col = xcd % tile_q;
     // Without spans: row part k is the k-th contiguous range of rows, walked in row order.  With spans -- the rows as
     // (row, start, end, info) sorted by decreasing length, built once per matrix on the host -- the groups of WAVES
     // positions (one workgroup each) are dealt to the row parts in turn: the longest rows start first and every XCD gets
     // an equal share of them.  (GL7d25 is sorted the other way round, every row longer than 128 entries among its last
     // 93: in row order they all start last and decide when the kernel ends.)
-    const uint32_t block = blockIdx.x >> 3;
+    const uint32_t block = bx >> 3;
     const uint32_t position = spans ? (block * (8u / tile_q) + part_row) * WAVES + wave : part_row * rows_per_part + block * WAVES + wave;
-    const uint32_t slab = (blockIdx.y * tile_q + part_col) * COLS;
+    const uint32_t slab = (by * tile_q + part_col) * COLS;
     // wave-uniform; the one workgroup barrier below is reached by the 4 waves of a shared row, which are all valid
     if ((spans ? block : block * WAVES + wave) >= rows_per_part || position >= M || slab >= N) return;
     const uint32_t li = lane % G;
@@ -388,6 +390,15 @@ __global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32
         }
     }
     if (mine) C[static_cast<size_t>(row) * ldc + slab + lane] = Acc::finish(total);
+}
+
+template <class Acc, int WAVES, int NB>
+__global__ __launch_bounds__(WAVES * 64) void csr_split(uint32_t M, const uint32_t *__restrict__ rowPtrs,
+                                                        const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals,
+                                                        const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
+                                                        float *__restrict__ C, uint32_t ldc, uint32_t tile_q,
+                                                        uint32_t rows_per_part, const uint32_t *__restrict__ spans) {
+    csr_split_body<Acc, WAVES, NB>(blockIdx.x, blockIdx.y, M, rowPtrs, colIdxs, vals, B, b_bytes, N, ldb, C, ldc, tile_q, rows_per_part, spans);
 }
 
 // ---- host side: what the CSR, COO and BSR-list entry points launch ---------------------------------------------------

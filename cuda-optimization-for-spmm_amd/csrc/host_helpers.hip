@@ -147,6 +147,27 @@ extern "C" int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPt
     return MISPMM_OK;
 }
 
+// Where a span list (mispmm_csr_spans_by_length_host: rows by decreasing length) divides into long rows for the split body
+// and short rows for the row-gather body of mispmm_csr_hybrid_f32: the first position whose row holds at most `threshold`
+// entries, rounded up to a multiple of 4 (positions are dealt to workgroups of 4 waves; the chunk groups of the longest
+// rows come first and are always covered).  numSpans itself when no row is that short.
+extern "C" int mispmm_csr_spans_long_count_host(uint32_t numSpans, const uint32_t *spans_host, uint32_t threshold, uint32_t *numLong_out) {
+    if (!numLong_out) return fail(MISPMM_ERR_INVALID_ARG, "csr spans long count: numLong_out is null");
+    *numLong_out = 0;
+    if (numSpans == 0) return MISPMM_OK;
+    if (!spans_host) return fail(MISPMM_ERR_INVALID_ARG, "csr spans long count: spans is null");
+    uint32_t p = 0;
+    while (p < numSpans) {
+        const uint32_t *span = spans_host + static_cast<size_t>(p) * 4u;
+        if (span[2] < span[1]) return fail(MISPMM_ERR_INVALID_ARG, "csr spans long count: span %u ends before it starts", p);
+        if (span[3] == 0 && span[2] - span[1] <= threshold) break;
+        ++p;
+    }
+    const uint64_t rounded = (static_cast<uint64_t>(p) + 3u) & ~3ull;
+    *numLong_out = rounded >= numSpans ? numSpans : static_cast<uint32_t>(rounded);
+    return MISPMM_OK;
+}
+
 extern "C" int mispmm_coo_sort_by_row_host(uint32_t M, uint32_t nnz, const uint32_t *rowIdxs_host,
                                            const uint32_t *colIdxs_host, const float *vals_host,
                                            uint32_t *rowIdxs_out_host, uint32_t *colIdxs_out_host,

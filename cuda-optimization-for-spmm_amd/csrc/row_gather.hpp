@@ -54,6 +54,14 @@ struct EllRows {
     }
 };
 
+// Rows named by a span list (row, start, end, info) as mispmm_csr_spans_by_length_host builds it: position i of the list is
+// the i-th row of this launch, its entries are colIdxs / vals [start, end) and its result goes to row `row` of C -- one
+// 16-byte read instead of two row pointers and a row map (the short rows of a long-row matrix, csr_hybrid in csr_split.hpp)
+struct SpanRows {
+    const uint32_t *spans;
+    static constexpr bool kPadded = false;
+};
+
 // Batched launch (mispmm_csr_batch_f32): blockIdx.z picks one of up to kMaxBatch dense operand / result pairs, all
 // multiplied by the same A in ONE launch -- what separates two dependent launches on this chip (~1.2 us of idle
 // between the last wave of one and the first of the next: profiles/r2/stamps_default.log) is paid once per batch.
@@ -72,7 +80,9 @@ template <int G, int VEC, class Acc, bool CBUF, class Rows, int BLOCK = 256, int
 #ifndef MISPMM_X_WAVES
 #define MISPMM_X_WAVES 5  // experiment builds: another register budget for the 8-reads-in-flight rolling body
 #endif
-__global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) void row_gather_kernel(
+// the kernel's body with the workgroup's grid position as arguments (bx, by, bz = blockIdx of a launch of its own; csr_hybrid
+// runs it on the workgroups behind those of the split body)
+__device__ __forceinline__ void row_gather_body(const uint32_t bx, const uint32_t by, const uint32_t bz,
     // the first 13 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count): they
     // are exactly what the wave needs to find its row and issue its first loads, so no wave starts
     // with a kernarg fetch in front of the row-pointer fetch
@@ -100,19 +110,19 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) 
     const float *__restrict__ B = B_one;
     float *__restrict__ C = C_one;
     if constexpr (BATCHED) {
-        B = batch.p.b[blockIdx.z];
-        C = batch.p.c[blockIdx.z];
+        B = batch.p.b[bz];
+        C = batch.p.c[bz];
     }
     constexpr int GROUPS = BLOCK / G;
     constexpr int U = G < UMAX ? G : UMAX;  // B reads in flight per lane; a row of <= U entries is ONE batch
     using vec_t = typename VecOf<VEC>::type;
     const uint32_t lane = threadIdx.x % G;
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t xcd = bx & 7u, slot = bx >> 3;
     const uint32_t log2p = tiling & 0xFFu;
     const uint32_t p = xcd & ((1u << log2p) - 1u), q = xcd >> log2p;
     const uint32_t row = (p * rb_chunk + slot) * GROUPS + threadIdx.x / G;
     const bool row_ok = row < M;
-    const uint32_t col0 = q * cols_per_part + blockIdx.y * (G * VEC) + lane * VEC;
+    const uint32_t col0 = q * cols_per_part + by * (G * VEC) + lane * VEC;
     const bool col_ok = col0 < min(N, (q + 1) * cols_per_part);
     size_t row_base = 0;
     uint32_t row_len = 0;
@@ -120,10 +130,20 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) 
     // path first needs them -- inside an `if (row_ok)` block hipcc waits for them on the spot, which would put the bet
     // on uniform rows (rolling body) behind the very hop it is meant to overlap
     uint32_t ptr_lo = 0, ptr_hi = 0;
+    // where this group's row goes in C (a row map is read behind the row's first (col, val) fetch: load_out_row below)
+    uint32_t out_row = row;
     if constexpr (std::is_same_v<Rows, CsrRows>) {
         const uint32_t rr = min(row, M - 1u);
         ptr_lo = rows.rowPtrs[rr];
         ptr_hi = rows.rowPtrs[rr + 1];
+    } else if constexpr (std::is_same_v<Rows, SpanRows>) {
+        if (row_ok) {
+            using u4 = uint32_t __attribute__((ext_vector_type(4)));
+            const u4 span = *reinterpret_cast<const u4 *>(rows.spans + static_cast<size_t>(row) * 4u);
+            out_row = span[0];
+            row_base = span[1];
+            row_len = span[2] - span[1];
+        }
     } else {
         if (row_ok) rows.extent(row, row_base, row_len);
     }
@@ -136,8 +156,6 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) 
     typename Acc::T acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0;
-    // where this group's row goes in C: read behind the row's first (col, val) fetch, needed only by the final store
-    uint32_t out_row = row;
     // (MAPPED is a template parameter on purpose: as a run-time test of the pointer it cost every launch of the unmapped
     // kernel 0.2 us on the headline -- a kernarg wait and a branch in front of the first B reads)
     auto load_out_row = [&] {
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) 
         const uint32_t wpb = blockDim.x / 64;
         const size_t waves_per_launch = static_cast<size_t>(gridDim.x) * gridDim.y * wpb;
         unsigned long long *o = mispmm_stamp_buf + (stamp_launch * waves_per_launch +
-            (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * wpb + (threadIdx.x >> 6)) * 8;
+            (static_cast<size_t>(by) * gridDim.x + bx) * wpb + (threadIdx.x >> 6)) * 8;
 #pragma unroll
         for (int i = 0; i < 5; ++i) o[i] = stamp[i];
         // where the wave ran: HW_REG_HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and HW_REG_XCC_ID (id 20)
@@ -401,10 +419,31 @@ __global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) 
 #endif
 }
 
+template <int G, int VEC, class Acc, bool CBUF, class Rows, int BLOCK = 256, int UMAX = 16, bool ROLL = false, int SLOTS = 16,
+          bool BATCHED = false, bool MAPPED = false>
+__global__ __launch_bounds__(BLOCK, ROLL ? (UMAX > 8 ? 3 : MISPMM_X_WAVES) : 1) void row_gather_kernel(
+    uint32_t M, uint32_t rb_chunk, uint32_t tiling, uint32_t cols_per_part, uint32_t N, uint32_t ldb, Rows rows,
+    const uint32_t *__restrict__ colIdxs, const float *__restrict__ vals, uint32_t b_bytes,
+    const float *__restrict__ B_one, float *__restrict__ C_one, uint32_t c_bytes, uint32_t ldc,
+    const uint32_t *__restrict__ rowMap, BatchArg<BATCHED> batch
+#ifdef MISPMM_STAMPS
+    , uint32_t stamp_launch
+#endif
+    ) {
+    row_gather_body<G, VEC, Acc, CBUF, Rows, BLOCK, UMAX, ROLL, SLOTS, BATCHED, MAPPED>(blockIdx.x, blockIdx.y, blockIdx.z, M, rb_chunk, tiling,
+                                                                                    cols_per_part, N, ldb, rows, colIdxs, vals, b_bytes, B_one,
+                                                                                    C_one, c_bytes, ldc, rowMap, batch
+#ifdef MISPMM_STAMPS
+                                                                                    , stamp_launch
+#endif
+    );
+}
+
 // ---- host side -------------------------------------------------------------------------------
 template <class Rows> constexpr const char *rows_tag() {
     if constexpr (std::is_same_v<Rows, CsrRows>) return "csr";
     else if constexpr (std::is_same_v<Rows, UniformRows>) return "uniform";
+    else if constexpr (std::is_same_v<Rows, SpanRows>) return "spans";
     else return "ell";
 }
 

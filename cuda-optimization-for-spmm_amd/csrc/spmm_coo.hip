@@ -10,6 +10,7 @@
 // Without a workspace each row group finds its range by binary search instead.
 #include "row_gather.hpp"
 #include "csr_split.hpp"
+#include "csr_hybrid.hpp"
 
 namespace mispmm {
 
@@ -228,6 +229,29 @@ extern "C" int mispmm_rows_split_f32(mispmm_stream_t stream, uint32_t M, uint32_
     if (pick_vec(B, ldb, C, ldc, N) != 4) return fail(MISPMM_ERR_UNSUPPORTED, "rows_split: B and C rows must be 16-byte vectors");
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_rows<AccRefF32>(as_stream(stream), M, K, nnz, nullptr, colIdxs, vals, B, N, ldb, C, ldc, 4, spans);
     else launch_rows<AccFast>(as_stream(stream), M, K, nnz, nullptr, colIdxs, vals, B, N, ldb, C, ldc, 4, spans);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+// The same list in one launch by two bodies (csr_hybrid.hpp): positions [0, numLongSpans) -- the long rows -- on the split
+// kernel's shape, the others by the row-gather body (a lane group per row, one running fp32 sum per element: the same
+// arithmetic in the same order).  MISPMM_ERR_UNSUPPORTED without a message where the shape has no such launch.
+extern "C" int mispmm_rows_hybrid_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
+                                      const uint32_t *spans, uint32_t numSpans, uint32_t numLongSpans, const float *B, uint32_t N,
+                                      uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "rows_hybrid: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!spans || !aligned16(spans)) return fail(MISPMM_ERR_INVALID_ARG, "rows_hybrid: spans is null or not 16-byte aligned");
+    if (numSpans != M) return fail(MISPMM_ERR_INVALID_ARG, "rows_hybrid: %u spans for %u rows (one per row: share_len = 0xFFFFFFFF)", numSpans, M);
+    if (numLongSpans > numSpans || (numLongSpans % 4u != 0 && numLongSpans != numSpans))
+        return fail(MISPMM_ERR_INVALID_ARG, "rows_hybrid: %u long spans of %u: a multiple of 4 is needed", numLongSpans, numSpans);
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "rows_hybrid: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull || pick_vec(B, ldb, C, ldc, N) != 4) return MISPMM_ERR_UNSUPPORTED;
+    const HybridArgs a{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc, spans, numSpans, numLongSpans};
+    const bool taken = acc_mode == MISPMM_ACC_REFERENCE ? launch_hybrid<AccRefF32>(a) : launch_hybrid<AccFast>(a);
+    if (!taken) return MISPMM_ERR_UNSUPPORTED;
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

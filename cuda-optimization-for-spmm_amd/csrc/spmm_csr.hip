@@ -19,6 +19,7 @@
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
 #include "row_gather.hpp"
 #include "csr_split.hpp"
+#include "csr_hybrid.hpp"
 
 namespace mispmm {
 
@@ -683,6 +684,31 @@ extern "C" int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t
     a.numSpans = numSpans;
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_split<AccRefWide>(a);
     else launch_split<AccFast>(a);
+    MISPMM_LAUNCH_CHECK();
+    return MISPMM_OK;
+}
+
+// The span list in one launch by two bodies (csr_hybrid.hpp): positions [0, numLongSpans) -- the long rows, a multiple of 4
+// that covers every chunk group (mispmm_csr_spans_long_count_host) -- through the split body, the others through the
+// row-gather body.  MISPMM_ERR_UNSUPPORTED (no message) where the shape has no such launch: take mispmm_csr_split_f32.
+extern "C" int mispmm_csr_hybrid_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
+                                     const uint32_t *spans, uint32_t numSpans, uint32_t numLongSpans, const float *B, uint32_t N,
+                                     uint32_t ldb, float *C, uint32_t ldc, int acc_mode) {
+    if (acc_mode != MISPMM_ACC_REFERENCE && acc_mode != MISPMM_ACC_FAST)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_hybrid: unknown accumulate mode %d", acc_mode);
+    if (M == 0 || N == 0) return MISPMM_OK;
+    if (!spans || !aligned16(spans)) return fail(MISPMM_ERR_INVALID_ARG, "csr_hybrid: spans must be a 16-byte aligned device array");
+    if (numSpans < M || (numSpans - M) % 3u != 0)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_hybrid: %u spans cannot describe %u rows (M + 3 per shared row)", numSpans, M);
+    if (numLongSpans > numSpans || (numLongSpans % 4u != 0 && numLongSpans != numSpans) || numLongSpans < ((numSpans - M) / 3u) * 4u)
+        return fail(MISPMM_ERR_INVALID_ARG, "csr_hybrid: %u long spans: a multiple of 4 that covers the %u chunk groups is needed", numLongSpans,
+                    (numSpans - M) / 3u);
+    if (nnz != 0 && (!colIdxs || !vals)) return fail(MISPMM_ERR_INVALID_ARG, "csr_hybrid: colIdxs or vals is null");
+    if (int s = check_dense_args(B, N, ldb, C, ldc)) return s;
+    if (static_cast<uint64_t>(K) * ldb * 4u > 0x7FFFFFFFull || pick_vec(B, ldb, C, ldc, N) != 4) return MISPMM_ERR_UNSUPPORTED;
+    const HybridArgs a{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc, spans, numSpans, numLongSpans};
+    const bool taken = acc_mode == MISPMM_ACC_REFERENCE ? launch_hybrid<AccRefWide>(a) : launch_hybrid<AccFast>(a);
+    if (!taken) return MISPMM_ERR_UNSUPPORTED;
     MISPMM_LAUNCH_CHECK();
     return MISPMM_OK;
 }

@@ -11,7 +11,13 @@ namespace cuspmm {
 // Device copy of the span list of a matrix whose rows are given by host row pointers (mispmm_csr_spans_by_length_host):
 // rows longest first; shareLen = 0 lets rows of more than 128 entries become 4 chunks (CSR arithmetic only),
 // 0xFFFFFFFF keeps one span per row (the fp32 arithmetic of COO / ELL / BSR).  Defined in sparse_csr.cpp.
-uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans);
+// Does a list with these row boundaries get a span list, and is it for the two-body launch only?  24 entries per row or more
+// on average: yes (the split kernel's domain).  Short rows on average but a row of 64 entries or more (tols4000: mean 2.2,
+// longest 90): yes, for mispmm_csr_hybrid_f32 / mispmm_rows_hybrid_f32 only -- a lane group walks a row of L entries in
+// L / 8 memory round trips, so those few rows decide the launch unless the split kernel's body takes them.
+bool wantsRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, bool &hybridOnly);
+// numLongSpans (optional): the leading positions that hold rows of more than 32 entries (mispmm_csr_spans_long_count_host)
+uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans, uint32_t *numLongSpans = nullptr);
 
 // ----------------------------------------------------------------------------------------------------
 // CSR matrix (/root/reference/include/formats/sparse_csr.hpp:11-39).
@@ -29,6 +35,10 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     // list mispmm_csr_split_f32 walks -- rows longest first, the longest as 4 chunks each (mispmm_csr_spans_by_length_host)
     MT *rowSpans = nullptr;
     MT numSpans = 0;
+    // the leading span positions that hold the rows of more than 32 entries: mispmm_csr_hybrid_f32 gives those to the split
+    // kernel's body and the others to the row-gather body of the same launch
+    MT numLongSpans = 0;
+    bool spansHybridOnly = false;  // short rows on average: the list serves the two-body launch, never the split kernel
     // device copies of a short-row matrix of 1024 rows or more whose rows cluster (mispmm_csr_cluster_rows_host cuts the
     // distinct columns per row part by 10 % or more): the same matrix with its rows in the clustered order, for
     // mispmm_csr_plan_f32 -- planRowMap[i] = the C row that array row i produces
@@ -64,6 +74,8 @@ template <typename _dataT, typename _metaT> class SparseMatrixCOO : public Spars
     bool rowBoundsReady = false;  // set once the boundaries of this device copy have been written
     // device only, for a COO of 24 entries per row or more: its rows as spans, longest first (mispmm_rows_split_f32)
     MT *rowSpans = nullptr;
+    bool rowSpansHybridOnly = false;
+    MT rowSpansLong = 0;  // its leading positions that hold rows of more than 32 entries (mispmm_rows_hybrid_f32)
 
     SparseMatrixCOO() = default;
     explicit SparseMatrixCOO(std::string filePath);
@@ -99,6 +111,8 @@ template <typename _dataT, typename _metaT> class SparseMatrixELL : public Spars
     DT *cpData = nullptr;
     MT cpCount = 0;
     MT *cpSpans = nullptr;  // ... and, from 24 occupied slots per row, its rows as spans, longest first
+    bool cpSpansHybridOnly = false;
+    MT cpSpansLong = 0;   // ... of which the leading positions hold rows of more than 32 occupied slots (mispmm_rows_hybrid_f32)
 
     SparseMatrixELL() = default;
     // files `<name>_rowind.ell` (header "rows cols nnz maxColNnz") and `<name>_values_colmajor.ell`
@@ -135,6 +149,8 @@ template <typename _dataT, typename _metaT> class SparseMatrixBSR : public Spars
     DT *nzVals = nullptr;
     MT nzCount = 0;
     MT *nzSpans = nullptr;  // from 24 list entries per row: the list's rows as spans, longest first (mispmm_rows_split_f32)
+    bool nzSpansHybridOnly = false;
+    MT nzSpansLong = 0;   // ... of which the leading positions hold rows of more than 32 entries (mispmm_rows_hybrid_f32)
 
     SparseMatrixBSR() = default;
     explicit SparseMatrixBSR(std::string filePath);

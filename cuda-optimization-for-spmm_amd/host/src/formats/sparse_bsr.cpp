@@ -98,9 +98,13 @@ template <typename DT, typename MT> SparseMatrixBSR<DT, MT> *SparseMatrixBSR<DT,
         copyBuffer(d->nzRowPtrs, true, rp.data(), false, rp.size() * sizeof(MT));
         copyBuffer(d->nzColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
         copyBuffer(d->nzVals, true, va.data(), false, va.size() * sizeof(DT));
-        if (this->numRows && nz / this->numRows >= 24) {
+        bool hybridOnly = false;
+        if (wantsRowSpans(this->numRows, rp.data(), hybridOnly)) {
             uint32_t count = 0;
-            d->nzSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count);
+            uint32_t longCount = 0;
+            d->nzSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count, &longCount);
+            d->nzSpansLong = longCount;
+            d->nzSpansHybridOnly = hybridOnly;
         }
     }
     return d;

@@ -77,15 +77,21 @@ template <typename DT, typename MT> SparseMatrixCOO<DT, MT> *SparseMatrixCOO<DT,
     copyBuffer(d->colIdxs, true, cols, false, (size_t)this->numNonZero * sizeof(MT));
     copyBuffer(d->data, true, vals, false, (size_t)this->numNonZero * sizeof(DT));
     // long rows: the row boundaries of the sorted entries as spans, longest first (one counting pass per upload)
-    if (this->numRows && this->numNonZero / this->numRows >= 24) {
+    if (this->numRows) {
         std::vector<uint32_t> rp((size_t)this->numRows + 1, 0);
         for (size_t i = 0; i < this->numNonZero; ++i) {
             if (rows[i] >= this->numRows) throw std::runtime_error("COO row index out of range");
             ++rp[(size_t)rows[i] + 1];
         }
         for (size_t r = 0; r < this->numRows; ++r) rp[r + 1] += rp[r];
-        uint32_t count = 0;
-        d->rowSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count);
+        bool hybridOnly = false;
+        if (wantsRowSpans(this->numRows, rp.data(), hybridOnly)) {
+            uint32_t count = 0;
+            uint32_t longCount = 0;
+            d->rowSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count, &longCount);
+            d->rowSpansLong = longCount;
+            d->rowSpansHybridOnly = hybridOnly;
+        }
     }
     return d;
 }

@@ -1,3 +1,4 @@
+#include <algorithm>
 #include "formats/sparse_csr.hpp"
 #include <type_traits>
 #include <vector>
@@ -47,13 +48,24 @@ template <typename DT, typename MT> bool SparseMatrixCSR<DT, MT>::allocateSpace(
     return true;
 }
 
-uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans) {
+bool wantsRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, bool &hybridOnly) {
+    hybridOnly = false;
+    if (numRows == 0 || rowPtrsHost[numRows] == 0) return false;
+    if (rowPtrsHost[numRows] / numRows >= 24) return true;
+    uint32_t longest = 0;
+    for (uint32_t r = 0; r < numRows; ++r) longest = std::max(longest, rowPtrsHost[r + 1] - rowPtrsHost[r]);
+    hybridOnly = true;
+    return longest >= 64;
+}
+
+uint32_t *uploadRowSpans(uint32_t numRows, const uint32_t *rowPtrsHost, uint32_t shareLen, uint32_t &numSpans, uint32_t *numLongSpans) {
     uint32_t count = 0;
     mispmmCheckError(mispmm_csr_spans_by_length_host(numRows, rowPtrsHost, shareLen, &count, nullptr));
     uint32_t *spans = allocateBuffer<uint32_t>((size_t)count * 4, false);
     mispmmCheckError(mispmm_csr_spans_by_length_host(numRows, rowPtrsHost, shareLen, &count, spans));
     uint32_t *dev = allocateBuffer<uint32_t>((size_t)count * 4, true);
     copyBuffer(dev, true, spans, false, (size_t)count * 4 * sizeof(uint32_t));
+    if (numLongSpans) mispmmCheckError(mispmm_csr_spans_long_count_host(count, spans, 32, numLongSpans));
     releaseBuffer(spans, false);
     numSpans = count;
     return dev;
@@ -71,10 +83,14 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     for (size_t r = 0; uniform && r <= this->numRows; ++r) uniform = this->rowPtrs[r] == (MT)(r * w);
     d->uniformRowNnz = uniform ? w : 0;
     // long rows: the split kernel wants them longest first (one counting sort per upload)
-    if (this->numRows && this->numNonZero / this->numRows >= 24) {
+    bool hybridOnly = false;
+    if (wantsRowSpans(this->numRows, this->rowPtrs, hybridOnly)) {
         uint32_t count = 0;
-        d->rowSpans = uploadRowSpans(this->numRows, this->rowPtrs, 0, count);
+        uint32_t longCount = 0;
+        d->spansHybridOnly = hybridOnly;
+        d->rowSpans = uploadRowSpans(this->numRows, this->rowPtrs, 0, count, &longCount);
         d->numSpans = count;
+        d->numLongSpans = longCount;
     } else if constexpr (std::is_same_v<DT, float>) {
         // short rows: keep a clustered row order when the greedy walk finds one (8 clusters: the best of 4 / 8 / 16 / 64 in the
         // K = 512 A/B, profiles/r3/plan_order.log); the wrapper multiplies from it where the product is bound by what the L2s fetch

@@ -92,9 +92,13 @@ template <typename DT, typename MT> SparseMatrixELL<DT, MT> *SparseMatrixELL<DT,
             copyBuffer(d->cpColIdxs, true, ci.data(), false, ci.size() * sizeof(MT));
             copyBuffer(d->cpData, true, va.data(), false, va.size() * sizeof(DT));
             d->cpCount = occupied;
-            if (occupied / this->numRows >= 24) {
+            bool hybridOnly = false;
+            if (wantsRowSpans(this->numRows, rp.data(), hybridOnly)) {
                 uint32_t count = 0;
-                d->cpSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count);
+                uint32_t longCount = 0;
+                d->cpSpans = uploadRowSpans(this->numRows, rp.data(), 0xFFFFFFFFu, count, &longCount);
+                d->cpSpansLong = longCount;
+                d->cpSpansHybridOnly = hybridOnly;
             }
         }
     }

@@ -56,7 +56,12 @@ DenseMatrix<DT, MT> *spmmBSRWrapper(int kernelNum, SparseMatrixBSR<DT, MT> *a, D
             const WrapperShape nzShape{"BSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->nzCount * n,
                                        a->nzCount * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
             return runWrapper<DT, MT>(nzShape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
-                if (a->nzSpans) {  // long rows: longest first
+                if (a->nzSpans && a->nzSpansLong > 0 && a->nzSpansLong < a->numRows) {  // the long rows on the split shape, the short ones by lane groups, one launch
+                    const int st = mispmm_rows_hybrid_f32(stream, a->numRows, a->numCols, a->nzCount, a->nzColIdxs, a->nzVals, a->nzSpans,
+                                                          a->numRows, a->nzSpansLong, b->data, b->numCols, b->numCols, c, ldc, acc);
+                    if (st != MISPMM_ERR_UNSUPPORTED) return st;
+                }
+                if (a->nzSpans && !a->nzSpansHybridOnly) {  // long rows: longest first
                     const int st = mispmm_rows_split_f32(stream, a->numRows, a->numCols, a->nzCount, a->nzColIdxs, a->nzVals, a->nzSpans,
                                                          a->numRows, b->data, b->numCols, b->numCols, c, ldc, acc);
                     if (st != MISPMM_ERR_UNSUPPORTED) return st;

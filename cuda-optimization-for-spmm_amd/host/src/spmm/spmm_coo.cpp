@@ -43,7 +43,12 @@ DenseMatrix<DT, MT> *spmmCOOWrapper(int kernelNum, SparseMatrixCOO<DT, MT> *a, D
             a->rowBoundsReady = true;
         }
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
-            if (a->rowSpans) {  // long rows: the spans carry the row boundaries, and the rows run longest first
+            if (a->rowSpans && a->rowSpansLong > 0 && a->rowSpansLong < a->numRows) {  // the long rows on the split shape, the short ones by lane groups, one launch
+                const int st = mispmm_rows_hybrid_f32(stream, a->numRows, a->numCols, a->numNonZero, a->colIdxs, a->data, a->rowSpans, a->numRows,
+                                                      a->rowSpansLong, b->data, b->numCols, b->numCols, c, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;
+            }
+            if (a->rowSpans && !a->rowSpansHybridOnly) {  // long rows: the spans carry the row boundaries, and the rows run longest first
                 const int st = mispmm_rows_split_f32(stream, a->numRows, a->numCols, a->numNonZero, a->colIdxs, a->data, a->rowSpans,
                                                      a->numRows, b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;

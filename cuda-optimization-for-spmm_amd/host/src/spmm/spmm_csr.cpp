@@ -65,7 +65,13 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
             // rows longest first
             const bool splits = kernelNum == 6 || ((kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5) &&
                                                    (acc == MISPMM_ACC_FAST || b->numCols < 384));
-            if (a->rowSpans && splits) {
+            if (a->rowSpans && splits && kernelNum != 6 && a->numLongSpans > 0 && a->numLongSpans < a->numSpans) {
+                // the long rows by the split kernel's body, the short ones by the row-gather body of the same launch
+                const int st = mispmm_csr_hybrid_f32(stream, a->numRows, a->numCols, a->numNonZero, a->colIdxs, a->data, a->rowSpans,
+                                                     a->numSpans, a->numLongSpans, b->data, b->numCols, b->numCols, c, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;  // shapes without such a launch take the split kernel on the whole list
+            }
+            if (a->rowSpans && splits && (kernelNum == 6 || !a->spansHybridOnly)) {
                 const int st = mispmm_csr_split_f32(stream, a->numRows, a->numCols, a->numNonZero, a->rowPtrs, a->colIdxs, a->data,
                                                     a->rowSpans, a->numSpans, b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;  // rows that are not 16-byte vectors take the general call

@@ -45,7 +45,12 @@ DenseMatrix<DT, MT> *spmmELLWrapper(int kernelNum, SparseMatrixELL<DT, MT> *a, D
                                  (double)a->numRows * a->rowWidth * 8.0 + a->numCols * n * 4 + a->numRows * n * 4};
         const int acc = accModeOf<AccT>();
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
-            if (a->cpSpans) {  // ... and long rows: longest first
+            if (a->cpSpans && a->cpSpansLong > 0 && a->cpSpansLong < a->numRows) {  // the long rows on the split shape, the short ones by lane groups, one launch
+                const int st = mispmm_rows_hybrid_f32(stream, a->numRows, a->numCols, a->cpCount, a->cpColIdxs, a->cpData, a->cpSpans, a->numRows,
+                                                      a->cpSpansLong, b->data, b->numCols, b->numCols, c, ldc, acc);
+                if (st != MISPMM_ERR_UNSUPPORTED) return st;
+            }
+            if (a->cpSpans && !a->cpSpansHybridOnly) {  // ... and long rows: longest first
                 const int st = mispmm_rows_split_f32(stream, a->numRows, a->numCols, a->cpCount, a->cpColIdxs, a->cpData, a->cpSpans,
                                                      a->numRows, b->data, b->numCols, b->numCols, c, ldc, acc);
                 if (st != MISPMM_ERR_UNSUPPORTED) return st;

@@ -57,6 +57,9 @@ SIGNATURES = {
     "mispmm_csr_batch_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),
     "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32), _vp]),
+    "mispmm_csr_hybrid_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
+    "mispmm_csr_spans_long_count_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32)]),
+    "mispmm_rows_hybrid_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_cluster_rows_host": (_i, [_u32, _u32, _vp, _vp, _u32, _vp, _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint64)]),
     "mispmm_csr_permute_rows_host": (_i, [_u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mispmm_csr_plan_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),

@@ -64,6 +64,33 @@ def csr_spans_by_length(row_ptrs, share_len=0):
     return spans
 
 
+HYBRID_ROW_LEN = 32   # rows of more entries go to the split body of mispmm_csr_hybrid_f32, the others to its row-gather body
+LONGEST_ROW_FOR_SPANS = 64   # a matrix of short rows with a row this long (tols4000: mean 2.2, longest 90) gets a span list too
+
+
+def wants_spans(row_ptrs):
+    """(build a span list, for the two-body launch only): long rows on average (24 entries or more: the split kernel's
+    domain), or short rows on average with a few long ones -- a lane group walks a row of L entries in L / 8 memory round
+    trips whatever the rest of the GPU does, so those few rows decide the launch; the two-body launch gives them to the
+    split kernel's body.  Without such a launch for the shape the second kind keeps its format's own kernel."""
+    rp = np.asarray(row_ptrs, dtype=np.int64)
+    m = rp.shape[0] - 1
+    if m <= 0 or rp[-1] == 0:
+        return False, False
+    if int(rp[-1]) // m >= 24:
+        return True, False
+    build = int(np.diff(rp).max()) >= LONGEST_ROW_FOR_SPANS
+    return build, build
+
+
+def spans_long_count(spans, threshold=HYBRID_ROW_LEN):
+    """How many leading positions of a span list hold the long rows (mispmm_csr_spans_long_count_host)."""
+    sp = np.ascontiguousarray(spans, dtype=np.uint32).reshape(-1, 4)
+    n = ctypes.c_uint32(0)
+    capi.check(capi.lib().mispmm_csr_spans_long_count_host(sp.shape[0], sp.ctypes.data, int(threshold), ctypes.byref(n)))
+    return n.value
+
+
 def cluster_rows(csr, parts=4):
     """Greedy row clustering (mispmm_csr_cluster_rows_host): (order, natural_distinct, clustered_distinct) -- order[i] = the
     original row at position i; the two counts are the distinct columns summed over `parts` equal row parts before / after."""
@@ -129,6 +156,8 @@ class DeviceCSR:
     uniform_row_nnz: int = 0     # > 0: structure hint checked on the host when A was uploaded
     spans: torch.Tensor = None   # rows longest first, for the split kernel; built at upload for long-row matrices
     plan: CsrPlan = None         # rows in a clustered order, kept when the clustering cuts the B rows an XCD must fetch
+    long_spans: int = 0          # leading positions of `spans` that hold the long rows (the split body of the two-body launch)
+    spans_hybrid_only: bool = False   # short rows on average: the list is for the two-body launch only, never the split kernel
 
     @staticmethod
     def from_host(csr, device="cuda", spans=None, share_len=0, plan=None):
@@ -137,9 +166,12 @@ class DeviceCSR:
         waves of a workgroup (0 = the library's default, 128).  plan: True / False to keep a clustered row order or not;
         None = when the matrix has short rows (no span list), at least 1024 rows, and the clustering cuts the distinct
         columns per row part by PLAN_MIN_GAIN or more (a once-per-upload analysis like the two above)."""
+        hybrid_only = False
         if spans is None:
-            spans = csr.num_rows > 0 and csr.nnz // csr.num_rows >= 24
-        sp = _dev_u32(csr_spans_by_length(csr.row_ptrs, share_len).reshape(-1), device) if spans else None
+            spans, hybrid_only = wants_spans(csr.row_ptrs)
+        sp_host = csr_spans_by_length(csr.row_ptrs, share_len) if spans else None
+        sp = _dev_u32(sp_host.reshape(-1), device) if spans else None
+        n_long = spans_long_count(sp_host) if spans else 0
         pl = None
         if plan or (plan is None and not spans and csr.num_rows >= 1024 and csr.nnz > 0):
             order, nat, clu = cluster_rows(csr, PLAN_PARTS)
@@ -148,7 +180,7 @@ class DeviceCSR:
                 pl = CsrPlan(_dev_u32(pc.row_ptrs, device), _dev_u32(pc.col_idxs, device), _dev_f32(pc.data, device),
                              _dev_u32(order, device), PLAN_PARTS, nat, clu)
         return DeviceCSR(csr.num_rows, csr.num_cols, csr.nnz, _dev_u32(csr.row_ptrs, device),
-                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp, pl)
+                         _dev_u32(csr.col_idxs, device), _dev_f32(csr.data, device), uniform_row_nnz(csr.row_ptrs), sp, pl, n_long, hybrid_only)
 
 
 @dataclass
@@ -204,16 +236,28 @@ class DeviceBSR:
 def _row_spans(row_ptrs, device):
     """One span per row, longest first (the fp32 arithmetic of COO / ELL / BSR cannot deal a row to several waves), for a
     list of 24 entries per row or more; else None."""
-    rp = np.asarray(row_ptrs, dtype=np.int64)
-    m = rp.shape[0] - 1
-    if m <= 0 or int(rp[-1]) // m < 24:
+    build, hybrid_only = wants_spans(row_ptrs)
+    if not build:
         return None
-    return _dev_u32(csr_spans_by_length(row_ptrs, 0xFFFFFFFF).reshape(-1), device)
+    host = csr_spans_by_length(row_ptrs, 0xFFFFFFFF)
+    dev = _dev_u32(host.reshape(-1), device)
+    dev.long_spans = spans_long_count(host)    # the positions the two-body launch gives to the split kernel's shape
+    dev.hybrid_only = hybrid_only              # short rows on average with a few long ones: the two-body launch or nothing
+    return dev
 
 
 def _rows_split(spans, num_rows, num_cols, nnz, col_idxs, data, b, c, acc, stream):
     """mispmm_rows_split_f32 if the operands allow it; False = take the format's own entry point."""
     if spans is None:
+        return False
+    n_long = getattr(spans, "long_spans", 0)
+    if 0 < n_long < num_rows and os.environ.get("MISPMM_NO_HYBRID") != "1":
+        st = capi.lib().mispmm_rows_hybrid_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(spans), num_rows, n_long,
+                                               _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
+        if st != capi.ERR_UNSUPPORTED:
+            capi.check(st)
+            return True
+    if getattr(spans, "hybrid_only", False):
         return False
     st = capi.lib().mispmm_rows_split_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(spans), num_rows,
                                           _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
@@ -275,9 +319,21 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
     # (REFERENCE mode: up to 383 columns)
     wants_split = int(kernel) == 6 or (int(kernel) in (0, 5) and (acc == "fast" or n < 384))
     if use_hint and os.environ.get("MISPMM_NO_HINT") != "1" and a.spans is not None and wants_split:
-        st = capi.lib().mispmm_csr_split_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),
-                                             _p(a.data), _p(a.spans), a.spans.numel() // 4, _p(b), n, _dense_ld(b), _p(c),
-                                             _dense_ld(c), capi.ACC_MODES[acc])
+        # kernel 0 / 5: the long rows by the split body and the short rows by the row-gather body of ONE launch, where the
+        # shape has such a launch (else, and for kernel 6 by name, the split kernel on the whole list)
+        if int(kernel) != 6 and 0 < a.long_spans < a.spans.numel() // 4 and os.environ.get("MISPMM_NO_HYBRID") != "1":
+            st = capi.lib().mispmm_csr_hybrid_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.col_idxs), _p(a.data),
+                                                  _p(a.spans), a.spans.numel() // 4, a.long_spans, _p(b), n, _dense_ld(b), _p(c),
+                                                  _dense_ld(c), capi.ACC_MODES[acc])
+            if st != capi.ERR_UNSUPPORTED:
+                capi.check(st)
+                return c
+        if a.spans_hybrid_only and int(kernel) != 6:
+            st = capi.ERR_UNSUPPORTED        # short rows on average: the wave-per-row split kernel is not for this matrix
+        else:
+            st = capi.lib().mispmm_csr_split_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs),
+                                                 _p(a.data), _p(a.spans), a.spans.numel() // 4, _p(b), n, _dense_ld(b), _p(c),
+                                                 _dense_ld(c), capi.ACC_MODES[acc])
         if st != capi.ERR_UNSUPPORTED:  # operands that are not 16-byte vectors take the general entry point below
             capi.check(st)
             return c

@@ -170,6 +170,23 @@ int mispmm_csr_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_
 int mispmm_csr_spans_by_length_host(uint32_t M, const uint32_t *rowPtrs_host, uint32_t share_len, uint32_t *count_out,
                                     uint32_t *spans_out_host);
 
+/* The same span list in ONE launch by two bodies (csr_hybrid.hpp): span positions [0, numLongSpans) -- the long rows --
+ * through the split kernel's body, the other positions -- the short rows, the tail of the list -- through the row-gather
+ * body (a lane group per row, the row's entries and its row of C named by its span).  On GL7d25 the split kernel spends
+ * 7.0 us where its 437 rows of more than 32 entries alone need 4.9 and the 2361 others 3.7 through the row-gather kernel
+ * (tools/probe/hybrid_longrows_probe.py); two launches would pay the launch boundary twice.  Same results as
+ * mispmm_csr_split_f32 in REFERENCE mode (the reference's bits: the row-gather body adds a row in entry order), FAST
+ * within its bound.  numLongSpans: a multiple of 4 that covers every 4-chunk group of the list; rows whose span lies
+ * behind it must be short enough for a lane group (mispmm_csr_spans_long_count_host: the first position whose row has
+ * at most `threshold` entries, rounded up to 4; the host layers use 32).
+ * Returns MISPMM_ERR_UNSUPPORTED, without a message and with nothing launched, for shapes without such a launch (more
+ * than 256 columns, column parts that are not one lane group wide, rows that are not 16-byte vectors, B or C of 2 GiB or
+ * more, no short rows): the caller takes mispmm_csr_split_f32.  New capability (no reference counterpart). */
+int mispmm_csr_hybrid_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
+                          const uint32_t *spans, uint32_t numSpans, uint32_t numLongSpans, const float *B, uint32_t N, uint32_t ldb,
+                          float *C, uint32_t ldc, int acc_mode);
+int mispmm_csr_spans_long_count_host(uint32_t numSpans, const uint32_t *spans_host, uint32_t threshold, uint32_t *numLong_out);
+
 /* Plan order: a CSR whose rows were PERMUTED once at upload so that rows which read the same B rows sit together --
  * the row-gather kernel gives each XCD a contiguous range of array rows and walks it in order, so a B row fetched for
  * one row of a cluster is still in that XCD's L2 for the others (n4c6-b13 x K=512, where a 6.5 MB B slice per XCD
@@ -263,6 +280,14 @@ int mispmm_ell_compact_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint3
 int mispmm_rows_split_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
                           const uint32_t *spans, uint32_t numSpans, const float *B, uint32_t N, uint32_t ldb, float *C,
                           uint32_t ldc, int acc_mode);
+/* mispmm_rows_split_f32's list in one launch by two bodies, as mispmm_csr_hybrid_f32 does for CSR: span positions
+ * [0, numLongSpans) on the split kernel's shape, the others by lane groups of the row-gather body -- the same fp32
+ * product and fp32 add in list order either way, so the same bits.  numLongSpans from
+ * mispmm_csr_spans_long_count_host (a multiple of 4).  MISPMM_ERR_UNSUPPORTED (no message, nothing launched) for shapes
+ * without such a launch: take mispmm_rows_split_f32. */
+int mispmm_rows_hybrid_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *colIdxs, const float *vals,
+                           const uint32_t *spans, uint32_t numSpans, uint32_t numLongSpans, const float *B, uint32_t N, uint32_t ldb,
+                           float *C, uint32_t ldc, int acc_mode);
 
 /* Zero-skipping BSR.  At BSR-16 the SuiteSparse matrices of data/ are ~98 % explicit zeros (ACTIVSg10K: 33 100 blocks
  * for 137 736 non-zeros): the dense block arithmetic of mispmm_bsr_f32 kernel 1 spends 84 us where the non-zeros

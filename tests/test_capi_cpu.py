@@ -254,6 +254,30 @@ def test_ell_compact_list_keeps_slot_order():
     assert l.mispmm_ell_compact_f32(None, 0, 4, 0, None, None, None, None, 8, 8, None, 8, 0) == capi.OK
 
 
+def test_span_list_divides_into_long_and_short_rows():
+    """mispmm_csr_spans_long_count_host: the leading positions of a span list that the two-body launch gives to the split
+    kernel's body -- every 4-chunk group, then the single spans of more than `threshold` entries, rounded up to a multiple of
+    4; everything when no row is that short; the whole list is never exceeded."""
+    from mispmm import ops
+    l = capi.lib()
+    for name, share, threshold in (("GL7d25", 0, 32), ("GL7d25", 40, 32), ("GL7d25", 0, 0), ("GL7d25", 0, 1000), ("tols4000", 0, 32),
+                                   ("n4c6-b13", 0, 13), ("n4c6-b13", 0, 14), ("Hamrle1", 0, 2)):
+        csr = datasets.load_csr(name)
+        spans = ops.csr_spans_by_length(csr.row_ptrs, share)
+        n_long = ops.spans_long_count(spans, threshold)
+        lens = (spans[:, 2] - spans[:, 1]).astype(np.int64)
+        is_long = (spans[:, 3] == 1) | (lens > threshold)
+        exact = int(is_long.sum())
+        assert is_long[:exact].all()                                  # the long ones are a prefix of the list
+        assert n_long == min(spans.shape[0], (exact + 3) // 4 * 4), (name, share, threshold)
+    n = ctypes.c_uint32(9)
+    assert l.mispmm_csr_spans_long_count_host(0, None, 32, ctypes.byref(n)) == 0 and n.value == 0
+    assert l.mispmm_csr_spans_long_count_host(3, None, 32, ctypes.byref(n)) == capi.ERR_INVALID_ARG
+    bad = np.array([[0, 5, 3, 0]], np.uint32)
+    assert l.mispmm_csr_spans_long_count_host(1, bad.ctypes.data, 32, ctypes.byref(n)) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_spans_long_count_host(1, bad.ctypes.data, 32, None) == capi.ERR_INVALID_ARG
+
+
 def test_rows_split_entry_validates_its_span_list():
     """mispmm_rows_split_f32 takes one span per row (the fp32 arithmetic cannot deal a row to several waves)."""
     l = capi.lib()

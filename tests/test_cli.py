@@ -165,8 +165,11 @@ def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
     assert [r["kernelType"] for r in recs] == ["0", "1", "2", "3", "4", "5", "6", "-1"]
     assert all(r["correct"] == "1" for r in recs)
     frac = {r["kernelType"]: float(r["rooflineFrac"]) for r in recs if "rooflineFrac" in r}
-    assert frac["6"] >= 0.18 and frac["5"] >= 0.18, frac
+    assert frac["6"] >= 0.18 and frac["5"] >= 0.25, frac
     assert max(frac[k] for k in ("1", "2", "3", "4")) < frac["6"], frac
+    # kernel 5 / the default: the two-body launch (kept: 5.1 us = 0.31); kernel 6 by name: the split kernel on every row
+    tags = {r["kernelType"]: r["kernel"] for r in recs if "kernel" in r}
+    assert "csr_hybrid" in tags.get("5", "") and "csr_split" in tags.get("6", ""), (tags, p.stdout[-1500:])
 
 
 @pytest.mark.gpu

@@ -253,7 +253,17 @@ def test_csr_split_row_kernel_on_real_matrices(oracle):
     for name in ("GL7d25", "tols4000", "n4c6-b13"):
         csr = datasets.load_csr(name)
         a = ops.DeviceCSR.from_host(csr, spans=True)
-        assert (ops.DeviceCSR.from_host(csr).spans is not None) == (name == "GL7d25")   # built unasked for long rows only
+        auto = ops.DeviceCSR.from_host(csr)
+        # built unasked for long rows (GL7d25: for the split kernel and the two-body launch) and for short rows with a few
+        # long ones (tols4000, longest 90: for the two-body launch only)
+        assert (auto.spans is not None, auto.spans_hybrid_only) == {"GL7d25": (True, False), "tols4000": (True, True), "n4c6-b13": (False, False)}[name]
+        if name == "tols4000":
+            b = synth.dense_b(csr.num_cols, 128)
+            ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+            assert np.array_equal(ops.spmm_csr(auto, dev(b)).cpu().numpy(), ref) and "csr_hybrid" in capi.last_kernel()
+            b = synth.dense_b(csr.num_cols, 96)              # no two-body launch for this width: the row-gather kernel, not the split kernel
+            ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+            assert np.array_equal(ops.spmm_csr(auto, dev(b)).cpu().numpy(), ref) and "row_gather" in capi.last_kernel()
         for n in (32, 128, 256, 516):
             b = synth.dense_b(csr.num_cols, n)
             ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
@@ -273,7 +283,55 @@ def test_csr_split_row_kernel_on_real_matrices(oracle):
     a = ops.DeviceCSR.from_host(csr)
     b = synth.dense_b(csr.num_cols, 128)
     assert np.array_equal(ops.spmm_csr(a, dev(b)).cpu().numpy(), oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b))
-    assert "longest-first" in capi.last_kernel()
+    assert "csr_hybrid" in capi.last_kernel()          # ... its long rows by the split body, the others by the row-gather body
+
+
+def test_csr_two_body_launch_for_long_row_matrices(oracle):
+    """mispmm_csr_hybrid_f32 (what kernel 0 takes on a matrix that carries a span list): the rows of more than 32 entries
+    through the split kernel's body, the others through the row-gather body of the SAME launch, both reading the one span
+    list.  REFERENCE mode returns the oracle's bits (and so the split kernel's), FAST stays within its bound; shapes
+    without such a launch (more than 256 columns, column parts that are not one lane group wide) take the split kernel."""
+    csr = datasets.load_csr("GL7d25")
+    a = ops.DeviceCSR.from_host(csr)
+    lens = np.diff(csr.row_ptrs.astype(np.int64))
+    spans = a.spans.cpu().numpy().view(np.uint32).reshape(-1, 4)
+    span_len = (spans[:, 2] - spans[:, 1]).astype(np.int64)
+    assert a.long_spans % 4 == 0 and np.all(span_len[a.long_spans:] <= 32) and np.all(spans[a.long_spans:, 3] == 0)
+    assert a.long_spans - 4 < int((spans[:, 3] == 1).sum()) + int((lens > 32).sum() - (lens > 128).sum()) <= a.long_spans
+    for n, hybrid in ((8, False), (32, True), (64, True), (96, False), (128, True), (256, True), (516, False)):
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+        got = ops.spmm_csr(a, dev(b))
+        assert ("csr_hybrid" in capi.last_kernel()) == hybrid, (n, capi.last_kernel())
+        assert np.array_equal(got.cpu().numpy(), ref), n
+        assert torch.equal(got, ops.spmm_csr(a, dev(b), kernel=6))             # the split kernel on the whole list: same bits
+        assert "csr_hybrid" not in capi.last_kernel()
+        fast = ops.spmm_csr(a, dev(b), acc="fast").cpu().numpy()
+        assert_fast_close(fast, ref, abs_scale(csr, b))
+        assert np.array_equal(fast, ops.spmm_csr(a, dev(b), acc="fast").cpu().numpy())   # deterministic
+    # values that make long rows fail the exactness test, an Inf and a NaN in B; a strided B and C whose gap survives
+    n, ld = 128, 140
+    rng = np.random.default_rng(3)
+    b = synth.dense_b(csr.num_cols, n)
+    b = (b * np.exp2(rng.integers(-30, 31, size=b.shape))).astype(np.float32)
+    b[csr.col_idxs[5], 0] = np.inf
+    b[csr.col_idxs[70000], 77] = np.nan
+    with np.errstate(all="ignore"):
+        ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    bw = torch.zeros((csr.num_cols, ld), dtype=torch.float32, device="cuda")
+    bw[:, :n] = dev(b)
+    cw = torch.full((csr.num_rows, ld), -7.0, dtype=torch.float32, device="cuda")
+    ops.spmm_csr(a, bw[:, :n], out=cw[:, :n])
+    assert "csr_hybrid" in capi.last_kernel()
+    assert np.array_equal(cw[:, :n].cpu().numpy(), ref, equal_nan=True) and torch.all(cw[:, n:] == -7.0)
+    # the entry point's own argument checks
+    l = capi.lib()
+    args = lambda n_long, n_spans=spans.shape[0]: (None, csr.num_rows, csr.num_cols, csr.nnz, a.col_idxs.data_ptr(), a.data.data_ptr(),  # noqa: E731
+                                                   a.spans.data_ptr(), n_spans, n_long, bw.data_ptr(), n, ld, cw.data_ptr(), ld, 0)
+    assert l.mispmm_csr_hybrid_f32(*args(a.long_spans + 2)) == capi.ERR_INVALID_ARG        # not a multiple of 4
+    assert l.mispmm_csr_hybrid_f32(*args(4)) == capi.ERR_INVALID_ARG                       # cuts through the chunk groups
+    assert l.mispmm_csr_hybrid_f32(*args(a.long_spans, spans.shape[0] + 1)) == capi.ERR_INVALID_ARG
+    assert l.mispmm_csr_hybrid_f32(*args(spans.shape[0] - spans.shape[0] % 4)) in (capi.ERR_UNSUPPORTED, 0)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -282,6 +340,7 @@ def test_csr_split_row_kernel_random_shapes(oracle, seed):
     giants among short rows, sorted either way, empty stretches), matrix and dense widths, value distributions of A and B
     (narrow, wide, sparse B, integers) -- REFERENCE mode must return the oracle's bits every time, FAST within its bound."""
     rng = np.random.default_rng(1000 + seed)
+    hybrids = 0
     for case in range(8):
         m = int(rng.integers(1, 700))
         k = int(rng.integers(8, 3000))
@@ -322,8 +381,13 @@ def test_csr_split_row_kernel_random_shapes(oracle, seed):
         assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6, use_hint=False).cpu().numpy(), ref), what
         assert np.array_equal(ops.spmm_csr(a, dev(b), kernel=6).cpu().numpy(), ref), what
         assert "longest-first" in capi.last_kernel()
+        # kernel 0: the two-body launch where the shape has one (the list's long rows split, its short rows by lane groups)
+        assert np.array_equal(ops.spmm_csr(a, dev(b)).cpu().numpy(), ref), what
+        hybrids += "csr_hybrid" in capi.last_kernel()      # (uniform rows, 384 columns or more, odd column parts go elsewhere)
         with np.errstate(all="ignore"):
             assert_fast_close(ops.spmm_csr(a, dev(b), kernel=6, acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+            assert_fast_close(ops.spmm_csr(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+    print(f"seed {seed}: {hybrids} of 8 cases took the two-body launch")
 
 
 def test_csr_split_row_kernel_takes_the_ordered_sum_only_where_needed(oracle, tmp_path):
@@ -511,7 +575,8 @@ def test_ell_mostly_padding_multiplies_from_the_occupied_slots(oracle):
         b = synth.dense_b(csr.num_cols, n)
         ref = oracle.spmm_ell_colmajor(ell.num_rows, ell.row_idxs, ell.data, b)
         assert np.array_equal(ops.spmm_ell(a, dev(b)).cpu().numpy(), ref), name
-        assert ("csr_split" in capi.last_kernel()) == split, capi.last_kernel()
+        # long rows: the two-body launch (split shape for the rows of more than 32 slots, lane groups for the others)
+        assert ("csr_hybrid<ref32" in capi.last_kernel()) == split, capi.last_kernel()
         padded = ops.DeviceELL.from_host(ell, compact=False)
         assert np.array_equal(ops.spmm_ell(padded, dev(b)).cpu().numpy(), ref), name
         assert_fast_close(ops.spmm_ell(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
@@ -590,7 +655,17 @@ def test_coo_and_bsr_list_long_rows_take_the_split_shape(oracle, n):
         for bb in ((b, wide, sparse_b) if mat is csr else (synth.dense_b(mat.num_cols, n),)):
             ref = oracle.spmm_coo(coo.num_rows, coo.row_idxs, coo.col_idxs, coo.data, bb)
             assert np.array_equal(ops.spmm_coo(a, dev(bb)).cpu().numpy(), ref)
-            assert "csr_split" in capi.last_kernel() and "ref32,longest-first" in capi.last_kernel()   # spans built at upload
+            # spans built at upload; where the width has a two-body launch (32-column parts) the rows of at most 32 entries
+            # go through the row-gather body of the same launch (mispmm_rows_hybrid_f32): same sums in the same order
+            two_body = n in (32, 64, 128, 256)
+            assert ("csr_hybrid<ref32" in capi.last_kernel()) if two_body else ("csr_split" in capi.last_kernel() and "ref32,longest-first" in capi.last_kernel())
+            if two_body:
+                os.environ["MISPMM_NO_HYBRID"] = "1"
+                try:
+                    assert np.array_equal(ops.spmm_coo(a, dev(bb)).cpu().numpy(), ref)
+                    assert "csr_split" in capi.last_kernel() and "ref32,longest-first" in capi.last_kernel()
+                finally:
+                    del os.environ["MISPMM_NO_HYBRID"]
             ws = ops.coo_row_bounds(a)
             assert np.array_equal(ops.spmm_coo(ops.DeviceCOO(a.num_rows, a.num_cols, a.nnz, a.row_idxs, a.col_idxs, a.data), dev(bb),
                                                workspace=ws, kernel=2).cpu().numpy(), ref)                  # no spans: rows in order
@@ -604,7 +679,7 @@ def test_coo_and_bsr_list_long_rows_take_the_split_shape(oracle, n):
     bb = synth.dense_b(gl.num_cols, n)
     ref = oracle.spmm_bsr(bsr.num_rows, 2, 2, bsr.block_row_ptrs, bsr.block_col_idxs, bsr.data, bb)
     assert np.array_equal(ops.spmm_bsr_nonzeros(nz, dev(bb)).cpu().numpy(), ref)
-    assert "csr_split" in capi.last_kernel() and "longest-first" in capi.last_kernel()
+    assert ("csr_hybrid<ref32" in capi.last_kernel()) if n in (32, 64, 128, 256) else ("csr_split" in capi.last_kernel() and "longest-first" in capi.last_kernel())
 
 
 def test_coo_with_empty_leading_and_trailing_rows(oracle):
