@@ -233,6 +233,14 @@ class DeviceBSR:
                          _dev_f32(bsr.data.reshape(-1), device))
 
 
+@dataclass
+class RowSpans:
+    """One span per row of a COO / ELL / BSR list, longest first, on the device (mispmm_rows_split_f32 / mispmm_rows_hybrid_f32)."""
+    spans: torch.Tensor
+    long_spans: int      # leading positions that hold rows of more than HYBRID_ROW_LEN entries: the split shape's share of the two-body launch
+    hybrid_only: bool    # short rows on average with a few long ones: the two-body launch or the format's own kernel, never the split kernel
+
+
 def _row_spans(row_ptrs, device):
     """One span per row, longest first (the fp32 arithmetic of COO / ELL / BSR cannot deal a row to several waves), for a
     list of 24 entries per row or more; else None."""
@@ -240,26 +248,23 @@ def _row_spans(row_ptrs, device):
     if not build:
         return None
     host = csr_spans_by_length(row_ptrs, 0xFFFFFFFF)
-    dev = _dev_u32(host.reshape(-1), device)
-    dev.long_spans = spans_long_count(host)    # the positions the two-body launch gives to the split kernel's shape
-    dev.hybrid_only = hybrid_only              # short rows on average with a few long ones: the two-body launch or nothing
-    return dev
+    return RowSpans(_dev_u32(host.reshape(-1), device), spans_long_count(host), hybrid_only)
 
 
-def _rows_split(spans, num_rows, num_cols, nnz, col_idxs, data, b, c, acc, stream):
-    """mispmm_rows_split_f32 if the operands allow it; False = take the format's own entry point."""
-    if spans is None:
+def _rows_split(rs, num_rows, num_cols, nnz, col_idxs, data, b, c, acc, stream):
+    """rs: RowSpans or None.  The two-body launch (mispmm_rows_hybrid_f32), else mispmm_rows_split_f32, if list and operands
+    allow it; False = take the format's own entry point."""
+    if rs is None:
         return False
-    n_long = getattr(spans, "long_spans", 0)
-    if 0 < n_long < num_rows and os.environ.get("MISPMM_NO_HYBRID") != "1":
-        st = capi.lib().mispmm_rows_hybrid_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(spans), num_rows, n_long,
-                                               _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
+    if 0 < rs.long_spans < num_rows and os.environ.get("MISPMM_NO_HYBRID") != "1":
+        st = capi.lib().mispmm_rows_hybrid_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(rs.spans), num_rows,
+                                               rs.long_spans, _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
         if st != capi.ERR_UNSUPPORTED:
             capi.check(st)
             return True
-    if getattr(spans, "hybrid_only", False):
+    if rs.hybrid_only:
         return False
-    st = capi.lib().mispmm_rows_split_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(spans), num_rows,
+    st = capi.lib().mispmm_rows_split_f32(_stream_ptr(stream), num_rows, num_cols, nnz, _p(col_idxs), _p(data), _p(rs.spans), num_rows,
                                           _p(b), b.shape[1], _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc])
     if st == capi.ERR_UNSUPPORTED:
         return False
@@ -275,7 +280,7 @@ class DeviceCOO:
     row_idxs: torch.Tensor
     col_idxs: torch.Tensor
     data: torch.Tensor
-    spans: torch.Tensor = None   # long rows: (row, start, end, 0) per row, longest first -- carries the row boundaries
+    spans: "RowSpans" = None     # long rows: (row, start, end, 0) per row, longest first -- carries the row boundaries
 
     @staticmethod
     def from_host(coo, device="cuda"):
