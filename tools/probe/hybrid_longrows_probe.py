@@ -55,6 +55,7 @@ def main():
     p.add_argument("--matrix", default="GL7d25")
     p.add_argument("--k-cols", type=int, default=128)
     p.add_argument("--acc", default="reference")
+    p.add_argument("--b-mode", default="uniform", help="--ab: synth.dense_b mode: uniform, or exact (a grid of values on which no wave's exactness test fails)")
     p.add_argument("--threshold", type=int, default=0, help="--ab: rows of more entries than this go to the split body (0 = the library's 32)")
     p.add_argument("--ab", action="store_true", help="only: the two-body launch (kernel 0) against the split kernel on the whole list (kernel 6), rounds interleaved")
     a = p.parse_args()
@@ -63,7 +64,7 @@ def main():
         dev_a = ops.DeviceCSR.from_host(csr)
         if a.threshold:
             dev_a.long_spans = ops.spans_long_count(ops.csr_spans_by_length(csr.row_ptrs), a.threshold)
-        b = torch.from_numpy(synth.dense_b(csr.num_cols, a.k_cols)).cuda()
+        b = torch.from_numpy(synth.dense_b(csr.num_cols, a.k_cols, mode=a.b_mode)).cuda()
         c = torch.empty((csr.num_rows, a.k_cols), device="cuda")
         stream = torch.cuda.Stream()
         res = {"two-body launch": [], "split kernel": []}
@@ -73,7 +74,7 @@ def main():
                 res[name].append(time_graph(lambda: ops.spmm_csr(dev_a, b, out=c, kernel=kernel, acc=a.acc, stream=stream), stream, rounds=3))
                 tags[name] = capi.last_kernel()
         base = np.median(res["split kernel"])
-        print(f"# {a.matrix} x K={a.k_cols} {a.acc} threshold {a.threshold or ops.HYBRID_ROW_LEN}: one process, one set of operands, rounds interleaved")
+        print(f"# {a.matrix} x K={a.k_cols} {a.acc} B {a.b_mode} threshold {a.threshold or ops.HYBRID_ROW_LEN}: one process, one set of operands, rounds interleaved")
         for name, t in res.items():
             print(f"{name:18s} {np.median(t):7.3f} us (min {min(t):.3f} max {max(t):.3f})  {100 * (np.median(t) / base - 1):+6.1f} %   {tags[name]}")
         return
