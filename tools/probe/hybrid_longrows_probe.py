@@ -57,8 +57,27 @@ def main():
     p.add_argument("--acc", default="reference")
     p.add_argument("--b-mode", default="uniform", help="--ab: synth.dense_b mode: uniform, or exact (a grid of values on which no wave's exactness test fails)")
     p.add_argument("--threshold", type=int, default=0, help="--ab: rows of more entries than this go to the split body (0 = the library's 32)")
+    p.add_argument("--force", action="store_true", help="only: the matrix's own kernel (no span list) against the two-body launch over a span list built anyway")
     p.add_argument("--ab", action="store_true", help="only: the two-body launch (kernel 0) against the split kernel on the whole list (kernel 6), rounds interleaved")
     a = p.parse_args()
+    if a.force:
+        # a matrix that gets no span list by itself: its own kernel against the two-body launch over a list built anyway
+        csr = datasets.load_csr(a.matrix)
+        lens = np.diff(csr.row_ptrs.astype(np.int64))
+        b = torch.from_numpy(synth.dense_b(csr.num_cols, a.k_cols)).cuda()
+        c = torch.empty((csr.num_rows, a.k_cols), device="cuda")
+        stream = torch.cuda.Stream()
+        plain, listed = ops.DeviceCSR.from_host(csr, spans=False), ops.DeviceCSR.from_host(csr, spans=True)
+        res, tags = {"own kernel": [], "two-body launch": []}, {}
+        for _ in range(3):
+            for name, dev_a in (("own kernel", plain), ("two-body launch", listed)):
+                res[name].append(time_graph(lambda: ops.spmm_csr(dev_a, b, out=c, acc=a.acc, stream=stream), stream, rounds=3))
+                tags[name] = capi.last_kernel()
+        base = np.median(res["own kernel"])
+        print(f"# {a.matrix} x K={a.k_cols} {a.acc}: mean row {lens.mean():.1f}, longest {lens.max()}, rows of more than 32 entries {(lens > 32).sum()}")
+        for name, t in res.items():
+            print(f"{name:18s} {np.median(t):7.3f} us (min {min(t):.3f} max {max(t):.3f})  {100 * (np.median(t) / base - 1):+6.1f} %   {tags[name]}")
+        return
     if a.ab:
         csr = datasets.load_csr(a.matrix)
         dev_a = ops.DeviceCSR.from_host(csr)
