@@ -56,6 +56,16 @@ __device__ __forceinline__ bool reassociation_is_exact(uint32_t len, float hi, u
     return len < (1u << 24) && hi < 0x1p100f && static_cast<float>(len) * hi <= 0x1p28f * smallest;
 }
 
+#ifdef MISPMM_STAMPS
+// Diagnostic build only (tools/stamp_split.py): every wave of the split body leaves s_memrealtime stamps (100 MHz) here:
+// 0 start, 1 span read, 2 split pass done, 3 partial sums reduced, 4 chunk hand-over barrier passed, 5 before the store
+// (after the chunk loop / an ordered pass), 6 end; word 7 = row length | shared << 32 | took the ordered pass << 33.
+static __device__ unsigned long long *mispmm_split_stamp_buf = nullptr;
+#define MISPMM_SPLIT_STAMP(i) sstamp[i] = wall_clock64()
+#else
+#define MISPMM_SPLIT_STAMP(i)
+#endif
+
 #ifdef MISPMM_TUNING
 // measurement build only: [0] waves that summed their row again in entry order since the last reset
 __device__ unsigned long long mispmm_split_stats[2];
@@ -94,6 +104,10 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
                                                const float *__restrict__ B, uint32_t b_bytes, uint32_t N, uint32_t ldb,
                                                float *__restrict__ C, uint32_t ldc, uint32_t tile_q, uint32_t rows_per_part,
                                                const uint32_t *__restrict__ spans) {
+#ifdef MISPMM_STAMPS
+    unsigned long long sstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    MISPMM_SPLIT_STAMP(0);
     using u2 = uint32_t __attribute__((ext_vector_type(2)));
     using T = typename Acc::T;
     constexpr bool kRef = std::is_same_v<Acc, AccRefWide>;
@@ -152,6 +166,19 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
         start = __builtin_amdgcn_readfirstlane(rowPtrs[row]);
         end = __builtin_amdgcn_readfirstlane(rowPtrs[row + 1]);
     }
+    MISPMM_SPLIT_STAMP(1);
+#ifdef MISPMM_STAMPS
+    const uint32_t stamp_len = end - start;
+    auto stamp_dump = [&](bool took_ordered) {
+        if (mispmm_split_stamp_buf && (threadIdx.x & 63u) == 0) {
+            sstamp[7] = static_cast<unsigned long long>(stamp_len) | (static_cast<unsigned long long>(shared) << 32) |
+                        (static_cast<unsigned long long>(took_ordered) << 33);
+            unsigned long long *o = mispmm_split_stamp_buf + (static_cast<size_t>(bx) * WAVES + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = sstamp[i];
+        }
+    };
+#endif
     u2 *const strip = reinterpret_cast<u2 *>(smem[wave]);
     T *const part = reinterpret_cast<T *>(smem[wave] + kStripBytes);
     float *const listed = reinterpret_cast<float *>(smem[wave] + kStripBytes);
@@ -286,6 +313,10 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
         return;
     }
     sweep(std::false_type{});
+#ifdef MISPMM_STAMPS
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+#endif
+    MISPMM_SPLIT_STAMP(2);
 
     // partial sums -> LDS, then lanes 0..31 add their column's 8 partial sums in group order
     wave_sync();
@@ -312,6 +343,7 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
             }
         }
     }
+    MISPMM_SPLIT_STAMP(3);
     bool need_ordered = false;
     if (shared) {
         // A long row as WAVES chunks, one per wave of this workgroup (the span list places them so): each wave hands its
@@ -331,7 +363,14 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
             reinterpret_cast<uint32_t *>(hand + kBounds)[1] = end;
         }
         __syncthreads();
-        if (wave != 0) return;
+        MISPMM_SPLIT_STAMP(4);
+        if (wave != 0) {
+#ifdef MISPMM_STAMPS
+            sstamp[5] = sstamp[6] = sstamp[4];
+            stamp_dump(false);
+#endif
+            return;
+        }
         // Chunk by chunk: as long as the union of the chunks so far passes the test, their sum is exact whatever the
         // order -- it IS the reference's running sum at that point -- so the ordered pass, if one is needed, starts at the
         // first chunk that breaks the test, from that sum, instead of at the row's first entry.
@@ -340,6 +379,10 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
         lo = 0xFFFFFFFFu;
         bool broken = false;
         uint32_t resume = start;
+        // (Tried on the stamps' evidence -- 0.9-1.0 us between the barrier and the store of a 4-chunk row -- and not kept: the
+        // hand-overs read in one batch of LDS reads (no change), and the whole row tested at once before this walk (that
+        // segment 0.92 -> 0.60 us at p90, the launch unchanged: what ends it are the shortest rows of the split body, dispatched
+        // last and reading under the load of the row-gather body; profiles/r3/stamps_split.log.)
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {  // wave order = entry order of the chunks
             const unsigned char *const from = smem[w] + kStripBytes;
@@ -389,7 +432,17 @@ __device__ __forceinline__ void csr_split_body(const uint32_t bx, const uint32_t
             total = ordered;
         }
     }
+#ifdef MISPMM_STAMPS
+    if (!shared) sstamp[4] = sstamp[3];
+    asm volatile("" : "+v"(total) : : "memory");
+#endif
+    MISPMM_SPLIT_STAMP(5);
     if (mine) C[static_cast<size_t>(row) * ldc + slab + lane] = Acc::finish(total);
+#ifdef MISPMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MISPMM_SPLIT_STAMP(6);
+    stamp_dump(need_ordered);
+#endif
 }
 
 template <class Acc, int WAVES, int NB>

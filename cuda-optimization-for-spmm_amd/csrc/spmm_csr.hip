@@ -713,6 +713,14 @@ extern "C" int mispmm_csr_hybrid_f32(mispmm_stream_t stream, uint32_t M, uint32_
     return MISPMM_OK;
 }
 
+#ifdef MISPMM_STAMPS
+// diagnostic build only: where the waves of the split body leave their stamps (8 x uint64 per wave, 4 waves per workgroup)
+extern "C" int mispmm_debug_set_stamps_split(void *device_buffer) {
+    MISPMM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mispmm_split_stamp_buf), &device_buffer, sizeof(device_buffer)));
+    return MISPMM_OK;
+}
+#endif
+
 // Several dense operands, one launch.  Only the row-gather kernel has a batched form; shapes it does not take
 // (a B of 2 GiB or more, rows too long for it, operands that are not 16-byte vectors) go out as one launch each.
 extern "C" int mispmm_csr_batch_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,

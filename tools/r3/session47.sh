@@ -1,0 +1,15 @@
+#!/bin/bash
+# the chunk hand-over read in one batch of LDS reads: parity of the split / two-body tests, stamps, A/B numbers
+set -o pipefail
+OUT=gpurun_out/r3s47
+mkdir -p $OUT
+P=cuda-optimization-for-spmm_amd
+timeout -k 10 900 python -m pytest tests/test_gpu_spmm.py -m gpu -x -q -k "split or two_body or long_row or coo_and_bsr" 2>&1 | tail -4 | tee $OUT/tests.log || exit 1
+MISPMM_LIB=$P/libmispmm_stamps.so timeout -k 10 300 python tools/stamp_split.py --acc reference 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stamps_split.log
+MISPMM_LIB=$P/libmispmm_stamps.so timeout -k 10 300 python tools/stamp_split.py --acc fast 2>&1 | grep -v amdgpu.ids | tee -a $OUT/stamps_split.log
+for acc in reference fast; do
+for n in 128 256; do
+timeout -k 10 300 python tools/probe/hybrid_longrows_probe.py --ab --acc $acc --k-cols $n 2>&1 | grep -v amdgpu.ids | tee -a $OUT/hybrid_ab.log
+done
+done
+echo done
