@@ -175,11 +175,11 @@ def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
 @pytest.mark.gpu
 def test_bench_line_perf_floors():
     """bench.py at the driver's flags: every BASELINE configuration must stay within a few percent of the kept numbers
-    (profiles/r3/bench_cfg*.json, fractions of the 8 TB/s roofline: headline 0.60-0.63, config 2 0.22, config 3 0.74,
+    (profiles/r3/bench_cfg*.json, fractions of the 8 TB/s roofline: headline 0.60-0.63, config 2 0.21-0.22, config 3 0.72-0.75,
     config 4 0.54 of the bytes its kernel moves, config 5 0.64), and the line must carry the contract's fields."""
     import json
     import sys
-    for cfg, floor in (("headline", 0.585), ("2", 0.20), ("3", 0.70), ("4", 0.51), ("5", 0.60)):
+    for cfg, floor in (("headline", 0.585), ("2", 0.20), ("3", 0.69), ("4", 0.51), ("5", 0.60)):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "20", "--warmup", "5",
                             "--cpu-seconds", "1", "--no-extras"], capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
