@@ -696,6 +696,10 @@ def run_multi(args):
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     capi.lib()
+    if args.config not in ("headline", "5"):
+        # the sharded path is BASELINE.json's: CSR rows over the GPUs (headline at N = 1, 2, 4, 8; configs[4] = K 512).  Refuse
+        # rather than print a CSR line under another configuration's name.
+        raise SystemExit(f"bench: --gpus N shards the CSR configurations (--config headline | 5); --config {args.config} is a single-GPU configuration")
     cfg_matrix = args.matrix or "n4c6-b13"
     n = args.k_cols or (512 if args.config == "5" else 128)
     csr = datasets.load_csr(cfg_matrix)
