@@ -278,6 +278,21 @@ def test_span_list_divides_into_long_and_short_rows():
     assert l.mispmm_csr_spans_long_count_host(1, bad.ctypes.data, 32, None) == capi.ERR_INVALID_ARG
 
 
+def test_which_matrices_get_a_span_list():
+    """ops.wants_spans (the rule both host layers apply at upload): 24 entries per row or more on average -> a span list for
+    the split kernel and the two-body launch; short rows on average but a row of 64 entries or more -> a list for the
+    two-body launch only; everything else none."""
+    from mispmm import ops
+    want = {"GL7d25": (True, False), "tols4000": (True, True)}
+    for name in datasets.DIR_TO_MATRIX.values():
+        assert ops.wants_spans(datasets.load_csr(name).row_ptrs) == want.get(name, (False, False)), name
+    assert ops.wants_spans(np.zeros(1, np.uint32)) == (False, False)
+    assert ops.wants_spans(np.array([0, 0, 0], np.uint32)) == (False, False)
+    assert ops.wants_spans(np.array([0, 64, 64, 65], np.uint32)) == (True, True)       # mean 21.7, longest 64
+    assert ops.wants_spans(np.array([0, 63, 63, 64], np.uint32)) == (False, False)
+    assert ops.wants_spans(np.array([0, 24, 48], np.uint32)) == (True, False)
+
+
 def test_rows_split_entry_validates_its_span_list():
     """mispmm_rows_split_f32 takes one span per row (the fp32 arithmetic cannot deal a row to several waves)."""
     l = capi.lib()
