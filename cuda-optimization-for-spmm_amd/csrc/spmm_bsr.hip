@@ -910,10 +910,12 @@ extern "C" int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockR
     // (measurement aid; buffer stores need C below 2 GiB, else plain)
     static const int store_knob = knob_int("MISPMM_BSR_STORE", 2);
     const int st = c_bytes <= 0x7FFFFFFFull ? store_knob : -1;
-    // no extra steps (every block row has at most 4): the kernel that deals the reduce and the store over the four waves
-    // (MISPMM_BSR_SHARE=0 keeps wave 0 doing both: measurement aid)
+    // no extra steps (every block row has at most 4) and an fp32 C: the kernel that deals the reduce and the store over the
+    // four waves.  With a bf16 C -- half the store volume, 4 instead of 8 store instructions for wave 0 -- dealing them out
+    // measured 6 % SLOWER (4.12 -> 4.37 us, profiles/r3/bsr_share_ab.log), with an fp32 C 5 % faster (4.73 -> 4.49).
+    // MISPMM_BSR_SHARE=0 / 2: never / whenever there are no extra steps (measurement aid).
     static const int share_knob = knob_int("MISPMM_BSR_SHARE", 1);
-    const bool share = share_knob != 0 && nSteps == numBlockRows * kBsrSlots;
+    const bool share = nSteps == numBlockRows * kBsrSlots && (share_knob == 2 || (share_knob == 1 && !c_bf16));
     note_kernel("bsrc_slots_mfma_bf16<%s,%s%s>", c_bf16 ? "c16" : "c32", st == 2 ? "nt" : st == 16 ? "sc1" : st == 18 ? "sc1nt" : "plain",
                 share ? ",share" : "");
 #define MISPMM_SLOTS_LAUNCH(CB, ST, SH)                                                                                            \

@@ -335,8 +335,8 @@ int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, 
  * padding column list -- so no pointer is read in front of a column list and the steps of a block row run on 4 waves
  * at once; steps past the fourth ("extra" steps, block rows with more than 128 occupied columns) follow the slots at
  * index 4 * numBlockRows + extraPtrs[R] .. extraPtrs[R + 1].  The 4 partial tiles are added in wave order through LDS
- * (fixed order: deterministic); where no block row has extra steps (config 4) each of the 4 waves adds and stores 4 of
- * the block row's 16 rows, else wave 0 does both -- the same bits either way.  mispmm_bsrc_bf16 walks the same steps
+ * (fixed order: deterministic); where no block row has extra steps and C is fp32 (config 4) each of the 4 waves adds and
+ * stores 4 of the block row's 16 rows, else wave 0 does both -- the same bits either way.  mispmm_bsrc_bf16 walks the same steps
  * with one wave per block row: 3 dependent memory hops per step on 1250 waves (config 4: 6.2 us); this layout needs 2 hops
  * and runs 5000 waves (4.5 us).
  * HOST helper (once per upload): outputs NULL = size query; *nSteps_out = 4 * numBlockRows + extra steps (array

@@ -1003,8 +1003,9 @@ def test_bsrc_slots_bf16_ragged_rows_extra_steps_and_strides(oracle):
 def test_bsrc_slots_shared_reduce_returns_the_bits_of_the_wave0_reduce():
     """Block rows of at most 4 steps (no extra steps: config 4) take the kernel instance that deals the reduce and the
     store over the four waves; it adds the partial tiles in the same wave order as the instance in which wave 0 does both
-    (what every layout with extra steps runs), so the two must agree bit for bit.  MISPMM_BSR_SHARE=0 (tuning build, read
-    once per process: child process) forces the latter."""
+    (what every layout with extra steps runs, and what a bf16 C keeps: there the shared reduce measured slower), so the two
+    must agree bit for bit.  MISPMM_BSR_SHARE=0 / 2 (tuning build, read once per process: child processes) force the latter /
+    the former for both C types; the default takes the shared reduce for an fp32 C only."""
     import subprocess
     import sys
     import tempfile
@@ -1019,21 +1020,26 @@ def test_bsrc_slots_shared_reduce_returns_the_bits_of_the_wave0_reduce():
         "    b = ops.f32_to_bf16(torch.from_numpy(synth.dense_b(csr.num_cols, n)).cuda())\n"
         "    for c16 in (0, 1):\n"
         "        out['%d_%d' % (n, c16)] = ops.spmm_bsrc_slots_bf16(a, b, out_bf16=bool(c16)).cpu().numpy()\n"
+        "        out['tag_%d_%d' % (n, c16)] = np.array(capi.last_kernel())\n"
         "np.savez(sys.argv[1], tag=np.array(capi.last_kernel()), **out)\n")
     tune = os.path.join(pkg, "libmispmm_tune.so")
     assert os.path.exists(tune), "run `make -C cuda-optimization-for-spmm_amd tune`"
     with tempfile.TemporaryDirectory() as tmp:
         res = {}
-        for share in ("0", "1"):
+        for share in ("0", "1", "2"):
             path = os.path.join(tmp, f"out{share}.npz")
             p = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MISPMM_BSR_SHARE=share, MISPMM_LIB=tune),
                                capture_output=True, text=True, timeout=600)
             assert p.returncode == 0, p.stderr[-2000:]
             res[share] = dict(np.load(path))
-        assert "share" in str(res["1"]["tag"]) and "share" not in str(res["0"]["tag"])
         for key in res["0"]:
-            if key != "tag":
-                assert np.array_equal(res["0"][key].view(np.uint8), res["1"][key].view(np.uint8)), key
+            if key.startswith("tag"):
+                continue
+            n, c16 = key.split("_")
+            assert "share" not in str(res["0"]["tag_" + key]) and "share" in str(res["2"]["tag_" + key]), key
+            assert ("share" in str(res["1"]["tag_" + key])) == (c16 == "0"), key          # the default: an fp32 C only
+            for other in ("1", "2"):
+                assert np.array_equal(res["0"][key].view(np.uint8), res[other][key].view(np.uint8)), (key, other)
 
 
 def bsr_to_dense(bsr, data):

@@ -17,12 +17,16 @@ VP, U32, I = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int
 
 
 def main():
+    c_bf16 = 0
+    if "--c-bf16" in sys.argv:
+        sys.argv.remove("--c-bf16")
+        c_bf16 = 1
     csr = datasets.load_csr("ACTIVSg10K")
     bsr = formats.csr_to_bsr(csr, 16)
     n = 128
     slots = ops.DeviceBSRCSlots.from_host(bsr)
     b16 = ops.f32_to_bf16(torch.from_numpy(synth.dense_b(csr.num_cols, n)).cuda())
-    c = torch.empty((csr.num_rows, n), device="cuda")
+    c = torch.empty((csr.num_rows, n), device="cuda", dtype=torch.int16 if c_bf16 else torch.float32)
     stream = torch.cuda.Stream()
     sp = VP(stream.cuda_stream)
     tmp = tempfile.mkdtemp()
@@ -44,14 +48,14 @@ def main():
 
         def call(lib=lib):
             st = lib.mispmm_bsrc_slots_bf16(sp, csr.num_rows // 16, csr.num_cols, slots.num_steps, VP(slots.extra_ptrs.data_ptr()),
-                                            VP(slots.cols.data_ptr()), VP(slots.tiles.data_ptr()), VP(b16.data_ptr()), n, n, VP(c.data_ptr()), n, 0)
+                                            VP(slots.cols.data_ptr()), VP(slots.tiles.data_ptr()), VP(b16.data_ptr()), n, n, VP(c.data_ptr()), n, c_bf16)
             assert st == 0, st
         call()
         torch.cuda.synchronize()
         got = c.clone()
         if ref is None:
             ref = got
-        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-2), name   # variants may add the partial tiles in another (fixed) order
+        assert torch.equal(got, ref) if c_bf16 else torch.allclose(got, ref, rtol=1e-4, atol=1e-2), name   # variants may add the partial tiles in another (fixed) order
         for k, v in saved.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         assert lib.mispmm_graph_begin(sp) == 0
@@ -76,7 +80,7 @@ def main():
             torch.cuda.synchronize()
             times[name].append(ev0.elapsed_time(ev1) * 1e3 / 4000)
     base = np.median(times[runs[0][0]])
-    print("# ACTIVSg10K BSR-16 x K=128 bf16, C fp32: one process, one set of operands, rounds interleaved")
+    print(f"# ACTIVSg10K BSR-16 x K=128 bf16, C {'bf16' if c_bf16 else 'fp32'}: one process, one set of operands, rounds interleaved")
     for name, _, _, tag in runs:
         t = np.array(times[name])
         print(f"{name:28s} {np.median(t):.3f} us (min {t.min():.3f} max {t.max():.3f})  {100 * (np.median(t) / base - 1):+.1f} %   {tag}")
