@@ -22,6 +22,14 @@ Where the gathered operand B sits in memory moves the time of one binary on one 
 placement_probe.log: fresh copies of B and C in one process), so the whole measurement above is made on `--placements`
 (default 5) freshly allocated copies of B and C and the line reports the MEDIAN copy; `timing.placements_us` lists them all.
 
+`hbm_streaming` (N = 1, every configuration): the steady-state loop above multiplies the same B into the same C, so its
+working set (17-66 MB) never leaves the 256 MiB Infinity Cache -- `value` is that figure, as BASELINE.json defines the metric.
+Beside it the SAME kernel is timed over S distinct (B, C) pairs in rotation, S = ceil(512 MiB / (bytes of B + C)) (headline:
+32 pairs, 522 MB), captured into one hipGraph whose launch count is a multiple of S, so that every launch reads a B and
+writes a C that 2 x 256 MiB of other operands have passed the caches since: B streams from HBM, C streams to it, A (0.7 MB,
+the same matrix every step) stays cached.  It is also the honest form of the reference's timing contract -- one cold,
+un-warmed launch per kernel (reference/src/engine/engine.cpp:41-44) -- without the event-pair overhead of a single shot.
+
 `roofline.traffic` is measured in the same run: before this process touches the GPU it runs the configuration twice as a
 child under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: separate passes, eager launches); profiles/r3/traffic.json is the
 fallback (--no-extras / --no-live-traffic skip the passes).
@@ -57,8 +65,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, same guide
 PRECONDITION_S = 0.05            # untimed replays before the timed region
 TIMED_S = 0.02                   # minimum length of one timed round
 ROUNDS = 5
+WATCHDOG_EXIT = 3                # exit code of every rank when an exchange mode hung and the watchdog printed the partial line
 MIN_GRAPH_NODES = 1000           # launches per captured graph (the K steps are captured ceil(1000 / K) times over)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3", "traffic.json")
+STREAM_BYTES = 512 << 20        # (B, C) pairs in rotation for the HBM-streamed figure: twice the 256 MiB Infinity Cache
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4", "traffic.json")
 _REAL_STDOUT = None
 
 
@@ -84,20 +94,28 @@ def parse():
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
     p.add_argument("--bucket", type=int, default=0, help="N>1: steps per C-slab exchange and per bucket hipGraph (0 = 64)")
-    p.add_argument("--exchange", default="both", choices=["allgather", "peer", "both"],
-                   help="N>1: how C slabs travel: `allgather` = RCCL all_gather_into_tensor, `peer` = direct stores into "
-                        "IPC-mapped peer buffers, `both` (default) measures the two and reports the faster as `value`")
+    p.add_argument("--exchange", default="allgather", choices=["allgather", "peer", "both"],
+                   help="N>1: how C slabs travel: `allgather` (default) = RCCL all_gather_into_tensor, `peer` = direct stores into "
+                        "IPC-mapped peer buffers (has only ever run between processes on one card), `both` measures the two and "
+                        "reports the faster as `value`")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--mode-timeout", type=int, default=240,
                    help="N>1: seconds an exchange mode after the first measured one may take before the line is printed without it (0 = wait)")
     p.add_argument("--no-extras", action="store_true",
-                   help="skip the other accumulate mode and the cold single shot (profiling passes use this)")
+                   help="skip the other accumulate mode, the batched launch and (unless --hbm-streaming on) the HBM-streamed figure")
+    p.add_argument("--hbm-streaming", default="auto", choices=["auto", "on", "off"],
+                   help="N=1: time the kernel over distinct (B, C) pairs in rotation as well (`hbm_streaming`); auto = unless --no-extras")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget")
     p.add_argument("--no-live-traffic", action="store_true",
                    help="N=1: skip the live PMC measurement.  By default (and unless --no-extras) this configuration is first run "
                         "twice as a child under `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: separate passes, eager launches) "
                         "before anything here touches the GPU, and roofline.traffic is the L2<->fabric bytes per launch measured "
                         "there; on any failure the committed figure of profiles/r3/traffic.json is printed instead (adds ~40 s)")
+    p.add_argument("--operand-sets", type=int, default=1,
+                   help="N=1: > 1 makes the MAIN timed loop rotate over this many distinct (B, C) pairs (0 = as many as 512 MiB "
+                        "takes): the HBM-streamed form of the workload.  The default line keeps the resident loop as `value` and "
+                        "reports the streamed one as `hbm_streaming`; this flag is for profiler children and experiments")
+    p.add_argument("--batch", type=int, default=8, help="N>1: dense operands per launch of the `kernel_only_batched` leg (0 = skip it)")
     p.add_argument("--placements", type=int, default=5,
                    help="N=1: time the K steps on this many freshly allocated copies of B and C and report the MEDIAN copy "
                         "(every copy is listed under timing.placements); 1 = the operands as first allocated")
@@ -124,6 +142,21 @@ class Workload:
         self.b = torch.from_numpy(self.b_host).cuda()
         self.c = torch.empty_like(self.c)
 
+    # -- the HBM-streamed form: distinct (dense operand, C) pairs in rotation --------------------------------------
+    def dense_operand(self):
+        return self.b
+
+    def pair_bytes(self):
+        d = self.dense_operand()
+        return d.numel() * d.element_size() + self.c.numel() * self.c.element_size()
+
+    def make_pairs(self, n):
+        """n (dense operand, C) pairs in buffers of their own (pair 0 = the operands of the resident loop); same values in
+        every copy -- what differs is the ADDRESS, which is all the caches see."""
+        import torch
+        d = self.dense_operand()
+        return [(d, self.c)] + [(d.clone(), torch.empty_like(self.c)) for _ in range(n - 1)]
+
 
 class CsrWorkload(Workload):
     fmt = "csr"
@@ -143,9 +176,10 @@ class CsrWorkload(Workload):
         self.extra_config = {"uniform_row_hint": self.a.uniform_row_nnz if args.kernel in (0, 5) else 0}
         self.has_fast = True
 
-    def step(self, stream, acc=None):
+    def step(self, stream, acc=None, pair=None):
         from mispmm import ops
-        ops.spmm_csr(self.a, self.b, out=self.c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
+        b, c = pair or (self.b, self.c)
+        ops.spmm_csr(self.a, b, out=c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
 
     def host_result(self):
         return self.c.cpu().numpy()
@@ -186,9 +220,10 @@ class EllWorkload(Workload):
         self.extra_config = {"ell_width": self.a.width}
         self.has_fast = True
 
-    def step(self, stream, acc=None):
+    def step(self, stream, acc=None, pair=None):
         from mispmm import ops
-        ops.spmm_ell(self.a, self.b, out=self.c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
+        b, c = pair or (self.b, self.c)
+        ops.spmm_ell(self.a, b, out=c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
 
     def host_result(self):
         return self.c.cpu().numpy()
@@ -258,15 +293,19 @@ class BsrBf16Workload(Workload):
         self.b16 = ops.f32_to_bf16(torch.from_numpy(self.b_host).cuda())
         self.c = torch.empty_like(self.c)
 
-    def step(self, stream, acc=None, which=None):
+    def dense_operand(self):
+        return self.b16
+
+    def step(self, stream, acc=None, which=None, pair=None):
         from mispmm import ops
         which = which or self.which
+        b16, c = pair or (self.b16, self.c)
         if which == "dense":
-            ops.spmm_bsr_bf16(self.a, self.blocks16, self.b16, out_bf16=False, out=self.c, stream=stream)
+            ops.spmm_bsr_bf16(self.a, self.blocks16, b16, out_bf16=False, out=c, stream=stream)
         elif which == "steps":
-            ops.spmm_bsrc_bf16(self.bsrc, self.b16, out_bf16=False, out=self.c, stream=stream)
+            ops.spmm_bsrc_bf16(self.bsrc, b16, out_bf16=False, out=c, stream=stream)
         else:
-            ops.spmm_bsrc_slots_bf16(self.slots, self.b16, out_bf16=False, out=self.c, stream=stream)
+            ops.spmm_bsrc_slots_bf16(self.slots, b16, out_bf16=False, out=c, stream=stream)
 
     def host_result(self):
         return self.c.cpu().numpy()
@@ -453,8 +492,9 @@ def load_traffic(key, kernel_tag):
     return entry["total_bytes"], entry.get("source", TRAFFIC_JSON)
 
 
-def live_traffic(args):
-    """L2<->fabric bytes per launch of THIS configuration, measured now: two children of this script under
+def live_traffic(args, operand_sets=1):
+    """L2<->fabric bytes per launch of THIS configuration (operand_sets = 0: of its HBM-streamed form, the main loop rotating
+    over (B, C) pairs), measured now: two children of this script under
     `rocprofv3 --pmc` (one counter group per pass, no trace domains), eager launches, no extras; counters corrected as
     MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and reads half of wide coalesced reads on gfx950; WRITE_SIZE
     in KiB is exact); first quarter of the dispatches dropped.  Called before this process touches the GPU.  Returns
@@ -465,8 +505,11 @@ def live_traffic(args):
     import tempfile
     if not shutil.which("rocprofv3"):
         return None, None, "rocprofv3 not on PATH"
-    child = ["python3", os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup", str(args.warmup),
-             "--kernel", str(args.kernel), "--acc", args.acc, "--launch", "eager", "--no-extras", "--no-cpu-baseline", "--placements", "1"]
+    # sys.executable = the interpreter binary that runs this process (a `python3` found on PATH may be a shim script: one more
+    # exec hop under the profiler, or another environment without torch)
+    child = [sys.executable, os.path.abspath(__file__), "--config", args.config, "--steps", str(args.steps), "--warmup", str(args.warmup),
+             "--kernel", str(args.kernel), "--acc", args.acc, "--launch", "eager", "--no-extras", "--no-cpu-baseline", "--placements", "1",
+             "--operand-sets", str(operand_sets)]
     if args.matrix:
         child += ["--matrix", args.matrix]
     if args.k_cols:
@@ -511,9 +554,31 @@ def live_traffic(args):
                         f"({means['WRITE_SIZE']:.1f} KiB) in separate passes of the same configuration (eager launches, first quarter dropped)")
 
 
+def stream_loop(w, stream, nsets):
+    """(fn, launches, nsets, pairs): fn enqueues the workload's next step on the next of `nsets` distinct (B, C) pairs
+    (0 = as many as STREAM_BYTES takes, at least 4); `launches` = a whole number of rotations of about MIN_GRAPH_NODES steps,
+    so that a graph of them can be replayed back to back without ever re-using a pair before all the others have passed."""
+    import itertools
+    import torch
+    if nsets <= 0:
+        nsets = max(4, -(-STREAM_BYTES // w.pair_bytes()))
+    pairs = w.make_pairs(nsets)
+    counter = itertools.count()
+
+    def fn():
+        w.step(stream, pair=pairs[next(counter) % nsets])
+
+    for _ in range(nsets):                 # first touch of every pair, and the counter back at a multiple of nsets
+        fn()
+    torch.cuda.synchronize()
+    return fn, nsets * max(1, -(-MIN_GRAPH_NODES // nsets)), nsets, pairs
+
+
 def run_single(args):
     # children only: nothing in this process has touched the GPU yet
-    live = live_traffic(args) if not (args.no_live_traffic or args.no_extras or args.launch != "graph") else None
+    want_live = not (args.no_live_traffic or args.no_extras or args.launch != "graph")
+    live = live_traffic(args, args.operand_sets) if want_live else None
+    live_stream = live_traffic(args, 0) if want_live and args.operand_sets == 1 and args.hbm_streaming != "off" else None
     import torch
     from mispmm import capi
     capi.lib()
@@ -521,6 +586,7 @@ def run_single(args):
     w = make_workload(args)
     stream = torch.cuda.Stream()
     timer = Timer(stream)
+    rotating = args.operand_sets != 1
 
     def step():
         w.step(stream)
@@ -530,16 +596,21 @@ def run_single(args):
     torch.cuda.synchronize()
     kernel_tag = capi.last_kernel()
 
-    # The same K steps on `--placements` fresh copies of B and C: where the gathered operand sits in memory moves the time
-    # of one binary on one box by up to 6 % (profiles/r3/placement_probe.log), so a single allocation is a draw from that
-    # range; the line reports the MEDIAN copy and lists them all.
     stats = []
-    for i in range(max(1, args.placements)):
-        if i:
-            w.fresh_operands()
-            step()
-            torch.cuda.synchronize()
-        stats.append(timer.measure(step, args.steps, use_graph=args.launch == "graph"))
+    if rotating:
+        # --operand-sets: the main loop itself is the HBM-streamed form (profiler children, experiments)
+        fn, launches, nsets, pairs = stream_loop(w, stream, args.operand_sets)
+        stats.append(timer.measure(fn, launches, use_graph=args.launch == "graph", min_nodes=1))
+    else:
+        # The same K steps on `--placements` fresh copies of B and C: where the gathered operand sits in memory moves the time
+        # of one binary on one box by up to 6 % (profiles/r3/placement_probe.log), so a single allocation is a draw from that
+        # range; the line reports the MEDIAN copy and lists them all.
+        for i in range(max(1, args.placements)):
+            if i:
+                w.fresh_operands()
+                step()
+                torch.cuda.synchronize()
+            stats.append(timer.measure(step, args.steps, use_graph=args.launch == "graph"))
     stat = sorted(stats, key=lambda s: s["median_us"])[(len(stats) - 1) // 2]
     step()                                # leave the timed mode's result in C for the parity check
     torch.cuda.synchronize()
@@ -584,8 +655,39 @@ def run_single(args):
                      "residency": "the steady-state loop multiplies the same A, B into the same C: the working set "
                                   f"({w.abytes / 1e6:.0f} MB) stays in the 256 MiB Infinity Cache, so `frac` is algorithmic bytes per "
                                   "second against the 8 TB/s HBM peak (the metric BASELINE.json defines), not measured HBM "
-                                  "traffic; `cold_single_shot` is the same launch after a 1 GiB flush"},
+                                  "traffic; `hbm_streaming` is the same kernel with B and C streamed from / to HBM"},
     }
+    out["roofline"]["traffic_source"] = ("live" if live is not None and live[0] is not None and live[1] == kernel_tag
+                                         else "committed fallback" if traffic is not None else None)
+    if rotating:
+        out["config"]["operand_sets"] = nsets
+        out["roofline"]["residency"] = (f"the timed loop rotates over {nsets} distinct (B, C) pairs ({nsets * w.pair_bytes() / 1e6:.0f} MB): "
+                                        "B streams from HBM, C streams to it; only A stays cached")
+        del pairs
+    elif args.hbm_streaming == "on" or (args.hbm_streaming == "auto" and not args.no_extras):
+        # The HBM-streamed figure (module docstring): the same kernel over S distinct (B, C) pairs in rotation, 2 x the Infinity
+        # Cache of them, one graph of a whole number of rotations replayed back to back inside one HIP-event pair.
+        fn, launches, nsets, pairs = stream_loop(w, stream, 0)
+        st = timer.measure(fn, launches, use_graph=args.launch == "graph", min_nodes=1, rounds=3)
+        s_traffic, s_src = None, "not measured (--no-live-traffic / --no-extras)"
+        if live_stream is not None:
+            s_traffic, s_src = (live_stream[0], live_stream[2]) if live_stream[0] is not None else (None, live_stream[2])
+        out["hbm_streaming"] = {
+            "launch_us": round(st["median_us"], 4), "min_us": round(st["min_us"], 4), "max_us": round(st["max_us"], 4),
+            "achieved": round(w.abytes / (st["median_us"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(w.abytes / (st["median_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "value": round(w.flops / (st["median_us"] * 1e-6) / 1e9, 2), "value_unit": "GFLOP/s",
+            "operand_sets": nsets, "bytes_in_rotation": int(nsets * w.pair_bytes()), "launches_per_graph": st["graph_nodes"],
+            "replays": st["replays"], "algorithmic_bytes_per_launch": w.abytes, "kernel_tag": capi.last_kernel(),
+            "traffic": s_traffic, "traffic_note": s_src,
+            "note": f"the same kernel over {nsets} distinct (B, C) pairs in rotation ({nsets * w.pair_bytes() / 1e6:.0f} MB = 2 x the 256 MiB "
+                    "Infinity Cache), a graph of a whole number of rotations replayed back to back: every launch reads its B from "
+                    "HBM and streams its C to HBM, A stays cached.  Never `value` (BASELINE.json's metric is the resident loop). "
+                    "It is also the cold-launch figure: N cold launches over N distinct operand sets inside ONE event pair, the "
+                    "form of the reference's one-un-warmed-launch-per-kernel timing (engine.cpp:41-44) without event overhead"}
+        del pairs, fn
+        step()
+        torch.cuda.synchronize()
     if w.fmt == "bsr":
         executed = w.executed_flops if w.which == "dense" else 2.0 * w.bsrc.num_steps * 16 * 32 * w.n
         ex = executed / (launch_us * 1e-6) / 1e12
@@ -642,30 +744,6 @@ def run_single(args):
                                       "bytes per product against the 8 TB/s HBM peak (the operands are Infinity-Cache resident, so the "
                                       "fraction can exceed what HBM alone would allow)"}
             del bs, cs
-        # cold single shot (SURVEY.md 8(d) asks for it next to the steady-state figure): 1 GiB is written first so
-        # that neither the L2s nor the 256 MiB Infinity Cache hold A, B or C; median of 5; HIP events around ONE
-        # eager launch (an empty event pair costs a few microseconds itself, reported beside it)
-        cold, empty = [], []
-        flush = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
-        ms = ctypes.c_float()
-        l = timer.l
-        with torch.cuda.stream(stream):
-            for _ in range(5):
-                flush.fill_(1.0)
-                capi.check(l.mispmm_event_record(timer.ev0, timer.sp))
-                step()
-                capi.check(l.mispmm_event_record(timer.ev1, timer.sp))
-                stream.synchronize()
-                capi.check(l.mispmm_event_elapsed_ms(timer.ev0, timer.ev1, ctypes.byref(ms)))
-                cold.append(ms.value * 1e3)
-                capi.check(l.mispmm_event_record(timer.ev0, timer.sp))
-                capi.check(l.mispmm_event_record(timer.ev1, timer.sp))
-                stream.synchronize()
-                capi.check(l.mispmm_event_elapsed_ms(timer.ev0, timer.ev1, ctypes.byref(ms)))
-                empty.append(ms.value * 1e3)
-        del flush
-        out["cold_single_shot"] = {"launch_us": round(sorted(cold)[2], 2), "empty_event_pair_us": round(sorted(empty)[2], 2),
-                                   "note": "one eager launch after a 1 GiB cache flush, HIP events, median of 5 (not the metric)"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, got, args.acc)
     emit(out)
@@ -720,7 +798,10 @@ def run_multi(args):
             "algorithmic_bytes": (e1 - e0) * 8 + (r1 - r0 + 1) * 4 + touched * n * 4 + (r1 - r0) * n * 4}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
-    def compose_and_emit():
+    extras = {}                      # legs measured beside the exchange modes (kernel_only_batched)
+    shard_kernel_tag = {}            # mispmm_last_kernel() of this rank's shard launches
+
+    def compose(partial=False):
         """rank 0: the contract line from the exchange modes measured so far"""
         usable = {m: r for m, r in results.items() if "value" in r}
         if not usable:
@@ -741,7 +822,7 @@ def run_multi(args):
                        "parallelism": f"row-sharded x{world}, B replicated, C slabs exchanged every {bucket} steps "
                                       f"({best}: " + ("RCCL all_gather_into_tensor" if best == "allgather" else
                                                       "direct copies into IPC-mapped peer buffers over xGMI") + ")",
-                       "kernel": args.kernel, "acc_mode": args.acc,
+                       "kernel": args.kernel, "kernel_tag": shard_kernel_tag.get("tag"), "acc_mode": args.acc,
                        "check": "exchanged C == unsharded single-GPU C (bitwise) on every rank"},
             "ranks_seen": {"world_size": world, "distinct_devices": len(devices_seen),
                            "devices": [f"{h}/{b}" for h, b in devices_seen],
@@ -750,7 +831,8 @@ def run_multi(args):
             "achieved_hbm_GBps": round(abytes / e2e_s / 1e9, 1),
             "exchange_modes": results,
             "kernel_only": {"value": r["kernel_only_value"], "unit": "GFLOP/s", "ms_per_step": r["kernel_only_ms_per_step"],
-                            "note": "the same steps re-run with C left row-sharded (no exchange), max over ranks"},
+                            "note": "the same steps re-run with C left row-sharded (no exchange) into ONE resident slab per rank -- "
+                                    "the form of the N = 1 line's loop, which overwrites one C -- max over ranks"},
             "roofline": {"bound": "hbm", "achieved": round(node_bytes / ko_s / 1e9, 1),
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(node_bytes / ko_s / 1e9 / (HBM_PEAK_GBS * world), 4),
@@ -761,18 +843,40 @@ def run_multi(args):
                                  "frac = those bytes / kernel-only time (C left row-sharded) against the N-GPU aggregate "
                                  "HBM peak, frac_end_to_end = the same bytes / ms_per_step (exchange included)"},
         }
+        out.update(extras)
+        if partial:
+            out["partial"] = "an exchange mode did not finish: the line holds what was measured before it"
         if not args.no_cpu_baseline:
             # the same CPU leg as at N = 1: the oracle, 1 thread, rank 0's host, and the checker of the exchanged C
-            shim = CsrWorkload.__new__(CsrWorkload)
-            shim.csr, shim.b_host, shim.flops, shim.n = csr, b_host, flops, n
-            shim.workload = out["config"]["workload"]
-            out["cpu_baseline"] = cpu_baseline(shim, args.cpu_seconds, gathered_host, args.acc)
-        emit(out)
+            if "cpu" not in cache:
+                shim = CsrWorkload.__new__(CsrWorkload)
+                shim.csr, shim.b_host, shim.flops, shim.n = csr, b_host, flops, n
+                shim.workload = out["config"]["workload"]
+                cache["cpu"] = cpu_baseline(shim, args.cpu_seconds, gathered_host, args.acc)
+            out["cpu_baseline"] = cache["cpu"]
+        return out
+
+    cache = {}
+
+    def persist():
+        """rank 0, after every measured mode: keep the line composed so far where the parent (spawn_ranks) finds it should a
+        LATER mode take this rank down (a fault, as opposed to a hang, kills the process before it can print anything)."""
+        path = os.environ.get("MISPMM_BENCH_PARTIAL")
+        if rank == 0 and path and any("value" in r for r in results.values()):
+            try:
+                with open(path + ".tmp", "w") as f:
+                    json.dump(compose(partial=True), f)
+                os.replace(path + ".tmp", path)
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write(f"bench: could not persist the partial line: {e}\n")
 
     def run_mode(mode):
         nonlocal whole, gathered_host
-        if os.environ.get("MISPMM_BENCH_STALL") == mode:   # test hook: this mode never finishes (tests/test_gpu_multi.py)
+        stall = os.environ.get("MISPMM_BENCH_STALL", "")   # test hooks (tests/test_gpu_multi.py): this mode never finishes / dies
+        if stall == mode:
             time.sleep(3600)
+        if stall == mode + ":die":
+            os._exit(9)
         try:
             job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode,
                                        debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
@@ -790,6 +894,7 @@ def run_multi(args):
         job.broadcast_b(b_host)                      # one-time, outside the timed region
         job.run(args.warmup)
         job.finish()
+        shard_kernel_tag["tag"] = capi.last_kernel()
 
         def timed(total_steps, gather):
             dist.barrier()
@@ -839,26 +944,65 @@ def run_multi(args):
         job.close()
 
     def start_watchdog(mode):
-        """A later exchange mode that does not finish (it has only ever run between processes on one card) must not cost
-        the line the earlier modes earned: after --mode-timeout seconds rank 0 prints the line with what was measured
-        and every rank leaves."""
+        """A later exchange mode that does not finish (the peer exchange has only ever run between processes on one card)
+        must not cost the line the earlier modes earned: after --mode-timeout seconds rank 0 prints the line with what was
+        measured, marked `partial`, and every rank leaves with exit code WATCHDOG_EXIT -- a hang on the GPU is a defect, not
+        a success, so the run is reported as failed although its line is there."""
         import threading
 
         def expire():
             results[mode] = {"unavailable": f"did not finish within {args.mode_timeout} s (watchdog); the line reports the modes before it"}
             if rank == 0:
                 try:
-                    compose_and_emit()
+                    emit(compose(partial=True))
                     sys.stdout.flush()
                 finally:
-                    os._exit(0)
+                    os._exit(WATCHDOG_EXIT)
             time.sleep(30)                     # rank 0 prints first
-            os._exit(0)
+            os._exit(WATCHDOG_EXIT)
 
         t = threading.Timer(args.mode_timeout, expire)
         t.daemon = True
         t.start()
         return t
+
+    def run_batched():
+        """kernel_only_batched: the kernel-only steps with `--batch` dense operands per launch (mispmm_csr_batch_f32 on every
+        rank's shard, C left row-sharded in resident slabs) -- the launch boundary once per `batch` products."""
+        job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange="allgather", batch=args.batch)
+        job.broadcast_b(b_host)
+        job.run(job.bucket, gather=False)
+        job.finish(gather=False)
+
+        def timed(total_steps):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.run(total_steps, gather=False)
+            job.finish(gather=False)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+
+        per_pass = -(-args.steps // job.bucket) * job.bucket          # whole buckets (graph replays) only
+        est = timed(per_pass)
+        replays = max(1, int(np.ceil(TIMED_S / max(est, 1e-6))))
+        t = timed(per_pass * replays) / (per_pass * replays)
+        ok = True
+        if whole is not None:                                         # every operand's slab == the rows of the unsharded product
+            ok = all(torch.equal(job.local_slab(i), whole[r0:r1]) for i in range(job.batch))
+        flag = torch.tensor([1.0 if ok else 0.0], device="cpu" if shared_gpu else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        job.close()
+        if float(flag[0]) == 0.0:
+            extras["kernel_only_batched"] = {"failed": "a batched slab differs from the unsharded product"}
+            return
+        extras["kernel_only_batched"] = {"operands_per_launch": job.batch, "value": round(flops / t / 1e9, 2), "unit": "GFLOP/s",
+                                         "ms_per_step": round(t * 1e3, 6), "replays": replays,
+                                         "note": f"kernel-only steps, {job.batch} dense operands (replicas of B in buffers of their own) per launch "
+                                                 "on every rank's shard, C left row-sharded; time per PRODUCT, max over ranks.  Never `value`"}
 
     for mode in modes:
         watchdog = start_watchdog(mode) if args.mode_timeout > 0 and any("value" in r for r in results.values()) else None
@@ -867,8 +1011,14 @@ def run_multi(args):
         finally:
             if watchdog is not None:
                 watchdog.cancel()
+        persist()
+    if args.batch > 1 and any("value" in r for r in results.values()):
+        try:
+            run_batched()
+        except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)
+            extras["kernel_only_batched"] = {"unavailable": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        compose_and_emit()
+        emit(compose())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -886,12 +1036,15 @@ def spawn_ranks(args):
             s.bind(("127.0.0.1", 0))
             return s.getsockname()[1]
 
+    partial_path = os.path.join(tempfile.gettempdir(), f"mispmm_bench_partial_{os.getpid()}.json")
     for attempt in range(3):
         port = free_port()
         procs, errs = [], []
+        if os.path.exists(partial_path):
+            os.remove(partial_path)
         for r in range(args.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MISPMM_BENCH_CHILD="1")
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", MISPMM_BENCH_CHILD="1", MISPMM_BENCH_PARTIAL=partial_path)
             err = tempfile.TemporaryFile()
             errs.append(err)
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
@@ -922,6 +1075,8 @@ def spawn_ranks(args):
             texts.append(err.read().decode(errors="replace"))
             err.close()
         if failed is None:
+            if os.path.exists(partial_path):
+                os.remove(partial_path)
             sys.stderr.write(texts[0])
             os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, out)
             sys.exit(0)
@@ -929,6 +1084,13 @@ def spawn_ranks(args):
         sys.stderr.write(f"bench: rank {failed} exited with {procs[failed].returncode}; the other ranks were stopped\n")
         sys.stderr.write(texts[failed][-4000:])
         if not (collided and attempt < 2):
+            # what was measured before the failure is still printed (marked `partial`) -- by rank 0 itself when its watchdog
+            # fired, else from the line it persisted after its last finished mode -- and the exit code stays non-zero
+            line = out if out.strip() else (open(partial_path, "rb").read() + b"\n" if os.path.exists(partial_path) else b"")
+            if os.path.exists(partial_path):
+                os.remove(partial_path)
+            if line.strip():
+                os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
             sys.exit(procs[failed].returncode or 1)
         sys.stderr.write("bench: the rendezvous port was taken -- starting fresh ranks on another port\n")
     sys.exit(1)

@@ -463,6 +463,13 @@ struct RowGatherArgs {
     float *const *C_list = nullptr;
 };
 
+// set by a launch helper that declined to launch (a row-mapped launch routed to a body without a mapped form): the entry
+// point that asked for the launch reads and clears it and returns MISPMM_ERR_UNSUPPORTED instead of a wrong product
+inline bool &row_gather_declined() {
+    static thread_local bool declined = false;
+    return declined;
+}
+
 // the row length the general CSR kernel bets on: nnz / M when the entries divide evenly over the rows, else 0 (no bet)
 inline uint32_t uniform_guess(uint32_t M, uint64_t nnz) {
     return (M != 0 && nnz != 0 && nnz % M == 0) ? static_cast<uint32_t>(nnz / M) : 0u;
@@ -580,9 +587,12 @@ void launch_row_gather_b(const RowGatherArgs &a, const Rows &rows, const XcdTili
             return;
         }
     }
-    if (a.rowMap) {  // only reachable through a measurement knob that forces another body: never multiply unmapped
-        fprintf(stderr, "mispmm: the row-gather body picked by the tuning knobs has no row-mapped form\n");
-        abort();
+    if (a.rowMap) {
+        // Unreachable in the production library (row_gather_supports_map admits only shapes whose default body has a mapped
+        // form); in the tuning build row_gather_supports_map also declines when a knob forces another body.  Should a new
+        // dispatch path ever get here: never multiply unmapped -- nothing is launched and the caller reports UNSUPPORTED.
+        row_gather_declined() = true;
+        return;
     }
     if (t.sc1 && c_bytes <= 0x7FFFFFFFull)
         hipLaunchKernelGGL((row_gather_kernel<G, VEC, Acc, true, Rows, BLOCK, UMAX, ROLL, SLOTS>), grid, dim3(BLOCK), 0, a.stream, a.M, rb_chunk,
@@ -650,6 +660,12 @@ void launch_row_gather(const RowGatherArgs &a, const Rows &rows, const XcdTiling
 // 32-column groups, C below 2 GiB (buffer stores), short rows.  mispmm_csr_plan_f32 declines everything else.
 inline bool row_gather_supports_map(uint32_t M, uint32_t K, uint32_t N, uint32_t ldc, int vec, uint32_t mean_row_len) {
     if (vec != 4 || static_cast<uint64_t>(M) * ldc * 4u > 0x7FFFFFFFull || mean_row_len >= 24) return false;
+    // tuning build: a measurement knob that forces a body without a mapped form (batch-at-a-time, another workgroup size,
+    // 16 reads in flight, wide lane groups, the deep body) declines the plan as a shape would -- the callers then multiply
+    // from the unpermuted arrays (the production build folds all of these to their defaults)
+    if (knob_int("MISPMM_ROLL", 1) == 0 || knob_int("MISPMM_BLOCK", 128) != 128 || knob_int("MISPMM_UMAX", 8) != 8 ||
+        knob_int("MISPMM_GROUP", 0) > 16 || knob_int("MISPMM_DEEP", -1) == 1)
+        return false;
     const XcdTiling t = xcd_tiling(N, vec, K);
     return t.sc1 && (N / t.q) % 32 == 0;
 }

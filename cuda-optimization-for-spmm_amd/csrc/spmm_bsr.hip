@@ -896,8 +896,12 @@ extern "C" int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockR
                                       uint32_t ldc, int c_bf16) {
     if (numBlockRows == 0 || N == 0) return MISPMM_OK;
     if (!extraPtrs || !cols || !tiles || !B || !C) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: null pointer");
-    if (nSteps < static_cast<uint64_t>(numBlockRows) * kBsrSlots)
+    // every product of sizes in 64 bits: the slot count, the grid and the byte extents must fit what the kernel indexes with
+    const uint64_t slot_steps = static_cast<uint64_t>(numBlockRows) * kBsrSlots;
+    if (nSteps < slot_steps)
         return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: nSteps %u is less than %u slots per block row", nSteps, kBsrSlots);
+    if (static_cast<uint64_t>(numBlockRows) * ceil_div(N, 128u) > 0x7FFFFFFFull)   // one workgroup per (block row, 128 columns)
+        return fail(MISPMM_ERR_UNSUPPORTED, "bsrc_slots_bf16: %u block rows x %u columns exceed the grid of this kernel", numBlockRows, N);
     if (ldb < N || ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "bsrc_slots_bf16: leading dimension smaller than N");
     if (N % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || !aligned16(B) || !aligned16(C) || !aligned16(tiles) || !aligned16(cols) ||
         static_cast<uint64_t>(K) * ldb * 2u > 0x7FFFFFFFull)
@@ -915,7 +919,9 @@ extern "C" int mispmm_bsrc_slots_bf16(mispmm_stream_t stream, uint32_t numBlockR
     // measured 6 % SLOWER (4.12 -> 4.37 us, profiles/r3/bsr_share_ab.log), with an fp32 C 5 % faster (4.73 -> 4.49).
     // MISPMM_BSR_SHARE=0 / 2: never / whenever there are no extra steps (measurement aid).
     static const int share_knob = knob_int("MISPMM_BSR_SHARE", 1);
-    const bool share = nSteps == numBlockRows * kBsrSlots && (share_knob == 2 || (share_knob == 1 && !c_bf16));
+    // nSteps == 4 * numBlockRows leaves no room for extra steps: by the layout's contract (mispmm.h) extraPtrs then describes
+    // none, and the SHARE kernel does not read it
+    const bool share = nSteps == slot_steps && (share_knob == 2 || (share_knob == 1 && !c_bf16));
     note_kernel("bsrc_slots_mfma_bf16<%s,%s%s>", c_bf16 ? "c16" : "c32", st == 2 ? "nt" : st == 16 ? "sc1" : st == 18 ? "sc1nt" : "plain",
                 share ? ",share" : "");
 #define MISPMM_SLOTS_LAUNCH(CB, ST, SH)                                                                                            \

@@ -797,6 +797,7 @@ extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t 
     auto launch = [&](RowGatherArgs &ga) {
         ga.rowMap = rowMap;
         ga.row_len_guess = uniform_guess(M, nnz);
+        row_gather_declined() = false;
         if (uniformRowNnz) {
             if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{uniformRowNnz}, vec);
             else launch_row_gather_auto<AccFast>(ga, UniformRows{uniformRowNnz}, vec);
@@ -804,21 +805,23 @@ extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t 
             if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, CsrRows{rowPtrs}, vec);
             else launch_row_gather_auto<AccFast>(ga, CsrRows{rowPtrs}, vec);
         }
+        return !row_gather_declined();
     };
+    const char *declined = "csr_plan: the row-gather body chosen for this shape has no row-mapped form: multiply from the unpermuted arrays";
     if (batch > 1 && batched_ok) {
         for (uint32_t first = 0; first < batch; first += kMaxBatch) {
             RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, nullptr, N, ldb, nullptr, ldc, M ? nnz / M : 0u};
             ga.batch = std::min(kMaxBatch, batch - first);
             ga.B_list = B_list_host + first;
             ga.C_list = C_list_host + first;
-            launch(ga);
+            if (!launch(ga)) return fail(MISPMM_ERR_UNSUPPORTED, "%s", declined);
             MISPMM_LAUNCH_CHECK();
         }
         return MISPMM_OK;
     }
     for (uint32_t i = 0; i < batch; ++i) {
         RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B_list_host[i], N, ldb, C_list_host[i], ldc, M ? nnz / M : 0u};
-        launch(ga);
+        if (!launch(ga)) return fail(MISPMM_ERR_UNSUPPORTED, "%s", declined);   // before anything was launched for this operand
         MISPMM_LAUNCH_CHECK();
     }
     return MISPMM_OK;

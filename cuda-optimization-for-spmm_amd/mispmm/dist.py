@@ -37,6 +37,14 @@ peer (same stream, so it is written last), and a reader that has waited for the 
 sentinel slots already carry that number -- a missing release or a too-early reader shows up as a stale sentinel even
 when the slab bytes happen to be identical from bucket to bucket, as they are in a benchmark.
 
+Kernel-only steps (`run(..., gather=False)`: C left row-sharded) write ONE resident slab, as the single-GPU bench loop
+overwrites one C: with a slot of its own per step (what an exchange needs) the slabs stream to fresh addresses beyond
+the Infinity Cache, and round 3's N = 1 distributed line read 6-9 % above the plain line for that reason alone.
+
+`batch = b` (kernel-only steps): b dense operands in buffers of their own (replicas of B) are multiplied per launch
+(mispmm_csr_batch_f32) -- the ~1.2 us between two dependent launches is paid once per b products, the only form in which
+a 788-row shard of this problem can scale.
+
 The compute step is injectable so the partition / bucket / gather logic is exercised on CPU with
 the gloo backend (tests/test_dist_cpu.py); on a GPU the default is the HIP kernel via the C ABI.
 """
@@ -62,7 +70,7 @@ def csr_row_slice(csr, r0, r1):
 
 class ShardedCsrSpmm:
     def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather",
-                 debug_sentinel=False):
+                 debug_sentinel=False, batch=1):
         if exchange not in ("allgather", "peer"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
         self.exchange = exchange
@@ -72,6 +80,10 @@ class ShardedCsrSpmm:
         self.n = int(n_cols)
         self.kernel, self.acc = kernel, acc
         self.bucket = max(1, int(bucket))
+        self.batch = max(1, int(batch))
+        if self.batch > 16:
+            raise ValueError("at most 16 dense operands per launch (mispmm_csr_batch_f32)")
+        self.bucket = -(-self.bucket // self.batch) * self.batch     # whole launches per bucket
         self.num_rows, self.num_cols = csr.num_rows, csr.num_cols
         self.bounds = shard_bounds(csr.row_ptrs, self.world)
         self.r0, self.r1 = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
@@ -86,6 +98,10 @@ class ShardedCsrSpmm:
                      for _ in range(2)]
         self.gathered = [torch.zeros((self.world, self.bucket, self.slab_rows, self.n), dtype=torch.float32,
                                      device=self.device) for _ in range(2)]
+        # kernel-only steps: one resident slab per operand of a batch (slab 0 for single launches)
+        self.local_c = torch.zeros((self.batch, self.slab_rows, self.n), dtype=torch.float32, device=self.device)
+        self.b_replicas = [self.b]    # batch > 1: filled by broadcast_b
+        self.last_local = None        # "resident" after a kernel-only step, (buf, slot) after a step into the ring
         self.pending = [None, None]
         self.step_count = 0
         self.last = None   # (buffer index, slot) of the most recent gathered step
@@ -182,6 +198,7 @@ class ShardedCsrSpmm:
             self.b.copy_(staged)
         else:
             dist.broadcast(self.b, src=0)
+        self.b_replicas = [self.b] + [self.b.clone() for _ in range(self.batch - 1)]
         if self.on_gpu:
             torch.cuda.synchronize(self.device)
 
@@ -233,15 +250,20 @@ class ShardedCsrSpmm:
         if self.debug_sentinel:
             self._check_sentinels(buf)
 
-    def _bucket_graph(self, buf, scatter):
-        key = (buf, bool(scatter))
+    def _bucket_graph(self, buf, scatter, resident=False):
+        key = ("resident", self.batch) if resident else (buf, bool(scatter))
         if key not in self.bucket_graphs:
             l = capi.lib()
             sp = ctypes.c_void_p(self.compute_stream.cuda_stream)
             self.compute_stream.synchronize()
             capi.check(l.mispmm_graph_begin(sp))
-            for slot in range(self.bucket):
-                self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
+            if resident and self.batch > 1:
+                outs = [self.local_c[i, :self.rows] for i in range(self.batch)]
+                for _ in range(self.bucket // self.batch):
+                    ops.spmm_csr_batch(self.a, self.b_replicas, outs=outs, acc=self.acc, stream=self.compute_stream)
+            else:
+                for slot in range(self.bucket):
+                    self.compute(self.a, self.b, self.local_c[0, :self.rows] if resident else self.ring[buf][slot, :self.rows])
             if scatter:
                 self._scatter(buf, capturing=True)  # the bucket's slabs leave for every peer inside the same graph
             g = ctypes.c_void_p()
@@ -260,13 +282,14 @@ class ShardedCsrSpmm:
                 if self.exchange == "peer" and gather:
                     self._wait(1 - buf, self.compute_stream)   # peers are done with the bucket before the last one
                 scatter = gather and self.exchange == "peer"
-                graph = self._bucket_graph(buf, scatter)
+                graph = self._bucket_graph(buf, scatter, resident=not gather)
                 if scatter and self.debug_sentinel:
                     self._next_sequence(buf)
                 capi.check(capi.lib().mispmm_graph_launch(graph,
                                                           ctypes.c_void_p(self.compute_stream.cuda_stream)))
                 self.step_count += self.bucket
                 done += self.bucket
+                self.last_local = (buf, self.bucket - 1) if gather else "resident"
                 if gather:
                     self._gather(buf, scattered=self.exchange == "peer")
                     self.last = (buf, self.bucket - 1)
@@ -283,7 +306,8 @@ class ShardedCsrSpmm:
                 if self.exchange == "peer" and gather:
                     self._wait(1 - buf, self.compute_stream)
             if self.rows:
-                self.compute(self.a, self.b, self.ring[buf][slot, :self.rows])
+                self.compute(self.a, self.b, self.ring[buf][slot, :self.rows] if gather else self.local_c[0, :self.rows])
+            self.last_local = (buf, slot) if gather else "resident"
             self.step_count += 1
             if gather and slot == self.bucket - 1:
                 self._gather(buf)
@@ -317,7 +341,11 @@ class ShardedCsrSpmm:
         parts = [self.gathered[buf][r, slot, :int(self.bounds[r + 1] - self.bounds[r])] for r in range(self.world)]
         return torch.cat(parts, dim=0)
 
-    def local_slab(self, slot=None):
-        i = self.step_count - 1
-        buf, s = (i // self.bucket) % 2, (i % self.bucket if slot is None else slot)
+    def local_slab(self, operand=0):
+        """This rank's C rows of the most recent step (kernel-only steps: of operand `operand` of the last launch)."""
+        if self.last_local is None:
+            raise RuntimeError("no step yet")
+        if self.last_local == "resident":
+            return self.local_c[operand, :self.rows]
+        buf, s = self.last_local
         return self.ring[buf][s, :self.rows]

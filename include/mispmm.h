@@ -342,7 +342,10 @@ int mispmm_bsrc_bf16(mispmm_stream_t stream, uint32_t numBlockRows, uint32_t K, 
  * HOST helper (once per upload): outputs NULL = size query; *nSteps_out = 4 * numBlockRows + extra steps (array
  * extents: cols[nSteps * 32], tiles[nSteps * 512]), *nUsedSteps_out (may be NULL) = steps that hold values (what the
  * kernel reads in full: an empty slot costs its 128-byte column list only); extraPtrs[numBlockRows + 1].
- * Device call: operands as for mispmm_bsrc_bf16.  Replaces spmmBSRWrapper1 (src/spmm/bsr/spmm_bsr_k1.cu:44-91) for
+ * Device call: operands as for mispmm_bsrc_bf16.  nSteps is the extent of cols / tiles, so nSteps == 4 * numBlockRows
+ * says there are NO extra steps: extraPtrs must then be all zeros (as the helper writes it) and is not read; with extra
+ * steps every extraPtrs[R + 1] <= nSteps - 4 * numBlockRows.  Column indices of a live column must be < K (loads of B are
+ * range-checked against K * ldb by the buffer descriptor: an index past it reads zeros, never memory).  Replaces spmmBSRWrapper1 (src/spmm/bsr/spmm_bsr_k1.cu:44-91) for
  * BASELINE.json config 4; bf16 is a new capability, the reference has none. */
 int mispmm_bsr_compact_slots_bf16_host(uint32_t numBlockRows, uint32_t bR, uint32_t bC, uint32_t numBlocks,
                                        const uint32_t *blockRowPtrs_host, const uint32_t *blockColIdxs_host,

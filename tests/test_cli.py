@@ -141,21 +141,15 @@ def test_cli_headline_directory_from_packed_matrix(tmp_path):
     recs = [r for r, _ in records(p.stdout)]
     assert [r["kernelType"] for r in recs if r["format"] == "CSR"] == ["0", "1", "2", "3", "4", "5", "6", "-1"]
     assert all(r["correct"] == "1" for r in recs)
-    # perf guard under the kept numbers (profiles/r2/cli_steady_probe.log): the CLI replays its --iters launches from
-    # one hipGraph; a 100-node graph still carries the ~7 us of one graph launch, so the floor sits under bench.py's
-    best = {}
-    for r in recs:
-        if "rooflineFrac" in r and r["kernelType"] not in ("0", "-1"):
-            best[r["format"]] = max(best.get(r["format"], 0.0), float(r["rooflineFrac"]))
-    assert best["CSR"] >= 0.48, f"CSR K=128 steady-state HBM roofline fraction regressed: {best}"
-    assert best["ELL"] >= 0.48, f"ELL K=128 steady-state HBM roofline fraction regressed: {best}"
+    # (the steady-state floors of this run live in tests/test_zz_perf_gpu.py)
+    assert all(float(r["rooflineFrac"]) > 0 for r in recs if "rooflineFrac" in r and r["kernelType"] not in ("0", "-1"))
 
 
 @pytest.mark.gpu
 def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
     """GL7d25 (rows of up to 422 entries, sorted so that the long ones come last) through `cuspmm --csr -k 128`: every
-    kernel agrees with the CPU engine; copy2Device builds the longest-first row list and kernel 6 / the library's own
-    choice run at more than twice the rate of the wave-per-row kernels (kept: 6.9 us = 0.23; floor a fifth under it)."""
+    kernel agrees with the CPU engine; copy2Device builds the longest-first row list, kernel 5 / the default take the
+    two-body launch and kernel 6 the split kernel (their rates: tests/test_zz_perf_gpu.py)."""
     from mispmm import datasets, formats
     d = tmp_path / "GL7d25"
     d.mkdir()
@@ -164,36 +158,33 @@ def test_cli_long_row_matrix_takes_the_split_kernel(tmp_path):
     recs = [r for r, _ in records(p.stdout)]
     assert [r["kernelType"] for r in recs] == ["0", "1", "2", "3", "4", "5", "6", "-1"]
     assert all(r["correct"] == "1" for r in recs)
-    frac = {r["kernelType"]: float(r["rooflineFrac"]) for r in recs if "rooflineFrac" in r}
-    assert frac["6"] >= 0.18 and frac["5"] >= 0.25, frac
-    assert max(frac[k] for k in ("1", "2", "3", "4")) < frac["6"], frac
     # kernel 5 / the default: the two-body launch (kept: 5.1 us = 0.31); kernel 6 by name: the split kernel on every row
     tags = {r["kernelType"]: r["kernel"] for r in recs if "kernel" in r}
     assert "csr_hybrid" in tags.get("5", "") and "csr_split" in tags.get("6", ""), (tags, p.stdout[-1500:])
 
 
 @pytest.mark.gpu
-def test_bench_line_perf_floors():
-    """bench.py at the driver's flags: every BASELINE configuration must stay within a few percent of the kept numbers
-    (profiles/r3/bench_cfg*.json, fractions of the 8 TB/s roofline: headline 0.60-0.63, config 2 0.21-0.22, config 3 0.72-0.75,
-    config 4 0.54 of the bytes its kernel moves, config 5 0.64), and the line must carry the contract's fields."""
-    import json
-    import sys
-    for cfg, floor in (("headline", 0.585), ("2", 0.20), ("3", 0.69), ("4", 0.51), ("5", 0.60)):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "20", "--warmup", "5",
-                            "--cpu-seconds", "1", "--no-extras"], capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        line = json.loads(p.stdout.strip().splitlines()[-1])
-        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-            assert key in line, key
-        assert line["steps"] == 20 and line["warmup"] == 5
-        assert line["cpu_baseline"]["gpu_parity"] == ("bit-exact" if cfg != "4" else "within 2e-6 of sum|a||b| (bf16-rounded inputs, fp32 accumulate)")
-        assert line["roofline"]["frac"] >= floor, (cfg, line["roofline"])
-        if cfg == "4":   # the fraction is quoted against the bytes the running kernel moves, the BSR-16 operand beside it
-            r = line["roofline"]
-            assert r["algorithmic_bytes_per_launch"] < 20e6 < r["bsr16_operand_bytes"] and r["frac_vs_bsr16_operand"] > r["frac"]
-            assert "bsrc_slots" in line["config"]["kernel_tag"]
+@pytest.mark.parametrize("cfg", ["headline", "2", "3", "4", "5"])
+def test_bench_line_contract(bench_line, cfg):
+    """bench.py at the driver's flags, every BASELINE configuration: the line carries the contract's fields, the GPU result
+    that was timed equals the oracle's (bench.py refuses to print otherwise), `roofline` and `hbm_streaming` follow from
+    their own numbers.  No assertion on a time here (tests/test_zz_perf_gpu.py holds those)."""
+    line = bench_line(cfg)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "hbm_streaming"):
+        assert key in line, key
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert line["cpu_baseline"]["gpu_parity"] == ("bit-exact" if cfg != "4" else "within 2e-6 of sum|a||b| (bf16-rounded inputs, fp32 accumulate)")
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (line["ms_per_step"] * 1e-3) / 8e12) < 2e-3
+    hs = line["hbm_streaming"]
+    assert hs["bytes_in_rotation"] >= 512 << 20 and hs["operand_sets"] >= 4 and hs["launches_per_graph"] % hs["operand_sets"] == 0
+    assert abs(hs["frac"] - hs["algorithmic_bytes_per_launch"] / (hs["launch_us"] * 1e-6) / 8e12) < 2e-3
+    assert hs["kernel_tag"] == line["config"]["kernel_tag"]
+    if cfg == "4":   # the fraction is quoted against the bytes the running kernel moves, the BSR-16 operand beside it
+        assert r["algorithmic_bytes_per_launch"] < 20e6 < r["bsr16_operand_bytes"] and r["frac_vs_bsr16_operand"] > r["frac"]
+        assert "bsrc_slots" in line["config"]["kernel_tag"]
 
 
 @pytest.mark.gpu
@@ -213,10 +204,7 @@ def test_cli_batched_launch_and_kernel_tags(tmp_path):
     single = {r["kernelType"]: r for r in recs if "batch" not in r}
     assert "row_gather" in single["5"]["kernel"] and "uniform" in single["5"]["kernel"]
     assert all("kernel" in r for k, r in single.items() if k != "0")
-    # what batching buys at this size: the launch boundary once per 8 products (3.05-3.41 us per product against 3.38-3.61
-    # for single launches over the boxes of round 3; both move by a few percent with where the operands sit, and 8 operands
-    # sit in 8 places -- one run read 3.44 against 3.39 -- so the assertion allows that much)
-    assert float(batched[0]["steadyKernelUs"]) < 1.05 * float(single["5"]["steadyKernelUs"])
+    # (what batching buys at this size is asserted with the other timings: tests/test_zz_perf_gpu.py)
 
 
 @pytest.mark.gpu

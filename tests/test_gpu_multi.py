@@ -148,17 +148,42 @@ def test_sharded_driver_over_rccl_world_size_one(oracle, nccl_world_of_one, exch
     job.close()
 
 
-def _bench(*args, env=None):
+def test_sharded_driver_kernel_only_steps_resident_and_batched(oracle, nccl_world_of_one):
+    """Kernel-only steps (C left row-sharded) write ONE resident slab -- the single-GPU loop's form -- and with batch = b every
+    launch multiplies b replicas of B into b slabs (mispmm_csr_batch_f32): every slab equals the oracle's product, whole
+    buckets through the graph and the steps of a partial bucket eagerly; gathered steps afterwards are untouched by it."""
+    from mispmm import dist as mdist
+    csr = datasets.load_csr("n4c6-b13")
+    n = 128
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    for batch in (1, 4):
+        job = mdist.ShardedCsrSpmm(csr, n, device=torch.device("cuda", 0), bucket=6, batch=batch)
+        assert job.bucket % batch == 0 and job.bucket >= 6
+        job.broadcast_b(b)
+        job.local_c.fill_(-1.0)
+        job.run(2 * job.bucket + 1, gather=False)           # two graph-replayed buckets and one eager step
+        job.finish(gather=False)
+        for i in range(batch):
+            assert np.array_equal(job.local_slab(i).cpu().numpy(), ref), (batch, i)
+        job.run(job.bucket)
+        job.finish()
+        assert np.array_equal(job.gathered_c().cpu().numpy(), ref)
+        assert np.array_equal(job.local_slab().cpu().numpy(), ref)
+        job.close()
+
+
+def _bench(*args, env=None, expect_rc=0):
     e = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "MASTER_ADDR", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == expect_rc, (p.returncode, p.stderr[-3000:])
     return json.loads(p.stdout.strip().splitlines()[-1])
 
 
 def test_bench_distributed_path_single_rank_over_rccl():
-    line = _bench("--gpus", "1", "--steps", "40", "--warmup", "8", "--bucket", "8", env={"MISPMM_FORCE_DIST": "1"})
-    assert line["n_gpus"] == 1 and set(line["exchange_modes"]) == {"allgather", "peer"}     # `both` is the default
+    line = _bench("--gpus", "1", "--steps", "40", "--warmup", "8", "--bucket", "8", "--exchange", "both", env={"MISPMM_FORCE_DIST": "1"})
+    assert line["n_gpus"] == 1 and set(line["exchange_modes"]) == {"allgather", "peer"}
     assert all("value" in v for v in line["exchange_modes"].values()), line["exchange_modes"]
     # what the N > 1 line must carry for the judge: who took part, the CPU leg, per-device bytes summed
     seen = line["ranks_seen"]
@@ -168,36 +193,46 @@ def test_bench_distributed_path_single_rank_over_rccl():
     roof = line["roofline"]
     assert roof["algorithmic_bytes_per_launch"] == seen["per_rank"][0]["algorithmic_bytes"] == roof["single_gpu_algorithmic_bytes"]
     assert 0 < roof["frac_end_to_end"] <= roof["frac"] < 1
+    # the batched kernel-only leg: 8 operands per launch on the shard, every slab checked against the unsharded product
+    kb = line["kernel_only_batched"]
+    assert kb["operands_per_launch"] == 8 and kb["value"] > 0 and "partial" not in line
 
 
-def test_distributed_line_with_one_rank_agrees_with_the_plain_line():
-    """The N = 1 distributed line (MISPMM_FORCE_DIST=1: one rank, RCCL backend, bucket graphs, wall-clock timing between
-    barriers) and the plain N = 1 line (1000-launch graphs, HIP events) time the same kernel.  Buckets of 500 steps so
-    that the idle time between two hipGraphLaunch calls (~7 us) is spread as thin as in the plain line's 1000-launch
-    graphs.  What remains is a real difference of the workloads, not of the clocks: the sharded driver gives every step
-    of a bucket its own C slot (the bucket's slabs travel together), so C is streamed to fresh addresses -- 2 x 500 x
-    3.2 MB of ring, far beyond the 256 MB Infinity Cache -- while the plain line overwrites one cache-resident C:
-    measured 3.67 vs 3.47 us (+5.8 %, gpurun_out/r3s4).  The plain line is the median of 5 freshly allocated copies of
-    B and C, the distributed line is ONE allocation, and where the operands sit moves this kernel by +-3 % (3.38-3.61 us,
-    profiles/r3/placement_probe.log; a run with 3.455 plain / 3.743 distributed failed a bound on the median).  So the
-    bound asserted is 8 % around the RANGE of the plain line's own placements."""
-    plain = _bench("--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline")
-    dist1 = _bench("--gpus", "1", "--steps", "500", "--warmup", "20", "--bucket", "500", "--exchange", "allgather",
-                   "--no-cpu-baseline", env={"MISPMM_FORCE_DIST": "1"})
-    lo, hi = min(plain["timing"]["placements_us"]) * 1e-3, max(plain["timing"]["placements_us"]) * 1e-3
-    b = dist1["kernel_only"]["ms_per_step"]
-    assert 0.92 * lo <= b <= 1.08 * hi, (plain["timing"]["placements_us"], b)
+def test_distributed_line_with_one_rank_is_the_plain_line_s_workload():
+    """The N = 1 distributed line (MISPMM_FORCE_DIST=1: one rank, RCCL backend, bucket graphs) and the plain N = 1 line must
+    time the SAME workload before their times may be compared at all: same device kernel (kernel tag), same parity, and the
+    kernel-only steps overwrite ONE resident slab as the plain loop overwrites one C (round 3: a slot of its own per step
+    streamed C beyond the Infinity Cache and read 6-9 % slower for that reason alone).  Structural equality only here -- the
+    in-process timing ratio of the two loops lives with the other timing assertions in tests/test_zz_perf_gpu.py."""
+    plain = _bench("--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline", "--placements", "1")
+    dist1 = _bench("--gpus", "1", "--steps", "64", "--warmup", "8", "--bucket", "32", "--batch", "0",
+                   env={"MISPMM_FORCE_DIST": "1"})
+    assert set(dist1["exchange_modes"]) == {"allgather"}                         # the default: the peer exchange is opt-in
+    assert dist1["config"]["kernel_tag"] == plain["config"]["kernel_tag"]
+    assert dist1["cpu_baseline"]["gpu_parity"] == "bit-exact"
+    assert "resident" in dist1["kernel_only"]["note"] and "kernel_only_batched" not in dist1
+    assert dist1["roofline"]["algorithmic_bytes_per_launch"] == plain["roofline"]["algorithmic_bytes_per_launch"]
 
 
 def test_a_stuck_exchange_mode_does_not_cost_the_line():
     """`--exchange both` measures the RCCL all-gather first and the peer stores second.  The peer exchange has only ever
     run between processes on one card; should it hang on a real 8-GPU node, the watchdog prints the line with the modes
-    measured before it and ends every rank with exit code 0.  MISPMM_BENCH_STALL=peer makes the mode sleep forever."""
+    measured before it, marked `partial`, and ends every rank with a NON-ZERO exit code (a GPU hang is a defect: the run is
+    reported as failed, its line is still there).  MISPMM_BENCH_STALL=peer makes the mode sleep forever."""
     line = _bench("--gpus", "2", "--steps", "16", "--warmup", "4", "--bucket", "8", "--cpu-seconds", "1", "--mode-timeout", "5",
-                  env={"MISPMM_SHARE_GPU": "1", "MISPMM_BENCH_STALL": "peer"})
-    assert line["n_gpus"] == 2 and "value" in line["exchange_modes"]["allgather"]
+                  "--exchange", "both", env={"MISPMM_SHARE_GPU": "1", "MISPMM_BENCH_STALL": "peer"}, expect_rc=3)
+    assert line["n_gpus"] == 2 and "value" in line["exchange_modes"]["allgather"] and "partial" in line
     assert "watchdog" in line["exchange_modes"]["peer"]["unavailable"]
     assert line["value"] == line["exchange_modes"]["allgather"]["value"] and line["cpu_baseline"]["gpu_parity"] == "bit-exact"
+
+
+def test_a_rank_lost_in_a_later_mode_leaves_the_persisted_line():
+    """A FAULT in a later exchange mode (as opposed to a hang) kills the rank before it can print: rank 0 persisted the
+    line after the all-gather mode, and the parent prints that (marked `partial`) with a non-zero exit code.
+    MISPMM_BENCH_STALL=peer:die makes every rank exit hard inside the peer mode."""
+    line = _bench("--gpus", "2", "--steps", "16", "--warmup", "4", "--bucket", "8", "--cpu-seconds", "1", "--exchange", "both",
+                  env={"MISPMM_SHARE_GPU": "1", "MISPMM_BENCH_STALL": "peer:die"}, expect_rc=9)
+    assert "partial" in line and "value" in line["exchange_modes"]["allgather"] and "peer" not in line["exchange_modes"]
 
 
 def test_peer_exchange_between_two_processes_on_one_card():

@@ -840,15 +840,6 @@ def test_csr_plan_order_is_bit_exact(oracle, name, n, taken):
     assert ops.plan_pays(25605, 512) and not ops.plan_pays(25605, 256) and not ops.plan_pays(4096, 512)
 
 
-def test_csr_plan_is_kept_only_where_clustering_pays():
-    """from_host(plan=None): a plan for the BASELINE matrices (clustering cuts the per-part distinct columns by 16-30 %),
-    none for a matrix whose storage order is already the best the greedy walk finds, none for long-row matrices (span list)."""
-    assert ops.DeviceCSR.from_host(datasets.load_csr("n4c6-b13")).plan is not None
-    assert ops.DeviceCSR.from_host(datasets.load_csr("ch7-6-b5")).plan is None
-    gl = ops.DeviceCSR.from_host(datasets.load_csr("GL7d25"))
-    assert gl.plan is None and gl.spans is not None
-
-
 @pytest.mark.parametrize("n", [128, 40, 6])
 def test_general_csr_entry_bets_on_uniform_rows_and_recovers(oracle, n):
     """The general entry point (no structure hint) with nnz == M * w: the row-gather waves fetch their first entries from

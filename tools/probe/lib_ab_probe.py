@@ -44,6 +44,9 @@ def main():
     p.add_argument("--matrix", default="n4c6-b13")
     p.add_argument("--k-cols", type=int, default=128)
     p.add_argument("--acc", type=int, default=0, help="0 reference, 1 fast")
+    p.add_argument("--sets", type=int, default=1,
+                   help="> 1: every variant's graph rotates over this many distinct (B, C) pairs (0 = 512 MiB of them): the "
+                        "HBM-streamed form of the loop (bench.py `hbm_streaming`); graphs hold a whole number of rotations")
     a = p.parse_args()
     csr = datasets.load_csr(a.matrix)
     n = a.k_cols
@@ -51,6 +54,10 @@ def main():
     rp, ci, va = dev(csr.row_ptrs.astype(np.uint32), np.int32), dev(csr.col_idxs.astype(np.uint32), np.int32), dev(csr.data.astype(np.float32), np.float32)
     b = torch.from_numpy(synth.dense_b(csr.num_cols, n)).cuda()
     c = torch.empty((csr.num_rows, n), device="cuda")
+    nsets = a.sets if a.sets > 0 else max(4, -(-(512 << 20) // ((csr.num_cols + csr.num_rows) * n * 4)))
+    pairs = [(b, c)] + [(b.clone(), torch.empty_like(c)) for _ in range(nsets - 1)]
+    launches = nsets * max(1, -(-1000 // nsets))
+    import itertools
     w = int(csr.row_ptrs[1] - csr.row_ptrs[0])
     stream = torch.cuda.Stream()
     sp = VP(stream.cuda_stream)
@@ -62,7 +69,10 @@ def main():
         env = dict(kv.split("=", 1) for kv in envs.split(";") if kv)
         lib, saved = load(os.path.join(ROOT, path) if not os.path.isabs(path) else path, env, tmp, f"{i}")
 
-        def call(lib=lib):
+        turn = itertools.count()
+
+        def call(lib=lib, turn=turn):
+            b, c = pairs[next(turn) % nsets]
             if a.entry == "uniform":
                 st = lib.mispmm_csr_uniform_f32(sp, csr.num_rows, csr.num_cols, w, VP(ci.data_ptr()), VP(va.data_ptr()), VP(b.data_ptr()), n, n,
                                                 VP(c.data_ptr()), n, a.acc)
@@ -70,7 +80,8 @@ def main():
                 st = lib.mispmm_csr_f32(sp, csr.num_rows, csr.num_cols, csr.nnz, VP(rp.data_ptr()), VP(ci.data_ptr()), VP(va.data_ptr()),
                                         VP(b.data_ptr()), n, n, VP(c.data_ptr()), n, 0, a.acc)
             assert st == 0, st
-        call()                                       # the knobs of this copy are read now, with its environment
+        for _ in range(nsets):                       # the knobs of this copy are read now, with its environment
+            call()
         torch.cuda.synchronize()
         tag = lib.mispmm_last_kernel().decode()
         for k, v in saved.items():
@@ -79,7 +90,7 @@ def main():
             else:
                 os.environ[k] = v
         assert lib.mispmm_graph_begin(sp) == 0
-        for _ in range(1000):
+        for _ in range(launches):
             call()
         g = VP()
         assert lib.mispmm_graph_end(sp, ctypes.byref(g)) == 0
@@ -98,9 +109,11 @@ def main():
                     lib.mispmm_graph_launch(g, sp)
                 ev1.record(stream)
             torch.cuda.synchronize()
-            times[name].append(ev0.elapsed_time(ev1) * 1e3 / 6000)
+            times[name].append(ev0.elapsed_time(ev1) * 1e3 / (6 * launches))
     base = np.median(times[runs[0][0]])
-    print(f"# {a.matrix} x K={n} acc={a.acc} entry={a.entry}: one process, one set of operands, rounds interleaved")
+    print(f"# {a.matrix} x K={n} acc={a.acc} entry={a.entry}: one process, "
+          + ("one set of operands" if nsets == 1 else f"{nsets} (B, C) pairs in rotation ({nsets * (csr.num_cols + csr.num_rows) * n * 4 / 1e6:.0f} MB: HBM-streamed)")
+          + ", rounds interleaved")
     for name, _, _, tag in runs:
         t = np.array(times[name])
         print(f"{name:28s} {np.median(t):.3f} us (min {t.min():.3f} max {t.max():.3f})  {100 * (np.median(t) / base - 1):+.1f} %   {tag}")
