@@ -1012,6 +1012,7 @@ def run_multi(args):
             if watchdog is not None:
                 watchdog.cancel()
         persist()
+        dist.barrier()       # no rank enters the next mode (where a fault may take the job down) before rank 0 has persisted this one
     if args.batch > 1 and any("value" in r for r in results.values()):
         try:
             run_batched()

@@ -53,6 +53,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline bool aligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+inline uint64_t ceil_div64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 // XCD-aware workgroup order (device half: xcd_block() in spmm_common.hpp): blocks to launch and the
 // chunk to pass for `nblk` logical row blocks; chunk 0 = keep dispatch order.

@@ -18,6 +18,7 @@
 // Roofline: HBM (arithmetic intensity ~1.3 flop/B); algorithmic bytes per launch =
 //   nnz*8 + (M+1)*4 + K*N*4 + M*N*4   (SURVEY.md section 8(d)).
 #include "row_gather.hpp"
+#include "row_stream.hpp"
 #include "csr_split.hpp"
 #include "csr_hybrid.hpp"
 
@@ -637,6 +638,11 @@ extern "C" int mispmm_csr_uniform_f32(mispmm_stream_t stream, uint32_t M, uint32
         return fail(MISPMM_ERR_UNSUPPORTED, "csr_uniform: B of 2 GiB or more: use mispmm_csr_f32");
     const RowGatherArgs ga{as_stream(stream), M, K, colIdxs, vals, B, N, ldb, C, ldc};
     const int vec = pick_vec(B, ldb, C, ldc, N);
+    // more than one round of waves: the persistent row-walking launch (row_stream.hpp)
+    if (try_row_stream(ga, rowNnz, false, acc_mode == MISPMM_ACC_REFERENCE ? 0 : 2, vec, -1)) {
+        MISPMM_LAUNCH_CHECK();
+        return MISPMM_OK;
+    }
     if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{rowNnz}, vec);
     else launch_row_gather_auto<AccFast>(ga, UniformRows{rowNnz}, vec);
     MISPMM_LAUNCH_CHECK();
@@ -798,6 +804,7 @@ extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t 
         ga.rowMap = rowMap;
         ga.row_len_guess = uniform_guess(M, nnz);
         row_gather_declined() = false;
+        if (uniformRowNnz && try_row_stream(ga, uniformRowNnz, false, acc_mode == MISPMM_ACC_REFERENCE ? 0 : 2, vec, -1)) return true;
         if (uniformRowNnz) {
             if (acc_mode == MISPMM_ACC_REFERENCE) launch_row_gather_auto<AccRefWide>(ga, UniformRows{uniformRowNnz}, vec);
             else launch_row_gather_auto<AccFast>(ga, UniformRows{uniformRowNnz}, vec);

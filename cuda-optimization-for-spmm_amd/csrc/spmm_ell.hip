@@ -10,6 +10,7 @@
 // reference's spmmELLCpu reaches a given C row (spmm_ell.cpp:16-29), so REFERENCE mode is
 // bit-identical to it.  Roofline: HBM; algorithmic bytes = M*width*8 + K*N*4 + M*N*4.
 #include "row_gather.hpp"
+#include "row_stream.hpp"
 
 namespace mispmm {
 
@@ -78,6 +79,8 @@ static void launch_ell_v(const EllArgs &a, int vec) {
         return;
     }
     const RowGatherArgs ga{a.stream, a.M, a.K, a.colIdxs, a.vals, a.B, a.N, a.ldb, a.C, a.ldc};
+    // more than one round of waves: the persistent row-walking launch (row_stream.hpp)
+    if (try_row_stream(ga, a.width, true, std::is_same_v<Acc, AccFast> ? 2 : 1, vec, -1)) return;
     launch_row_gather_auto<Acc>(ga, EllRows{a.width}, vec);
 }
 

@@ -55,6 +55,31 @@ def random_csr(m, k, row_lens, seed):
     return formats.CSR(m, k, ptr, cols.astype(np.uint32), vals)
 
 
+def test_row_stream_forced_on_small_and_odd_shapes():
+    """row_stream.hpp (the persistent row-walking launch) forced on through the tuning build (MISPMM_STREAM=1): CSR with a
+    constant row length 9..16, ELL with padding, ragged workgroups, strided operands, plan order -- bit-exact against the
+    oracle in REFERENCE mode, within 1e-5 of sum|a||b| in FAST mode (tests/_row_stream_cases.py, a process of its own)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune = os.path.join(root, "cuda-optimization-for-spmm_amd", "libmispmm_tune.so")
+    assert os.path.exists(tune), "run `make -C cuda-optimization-for-spmm_amd tune`"
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_row_stream_cases.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MISPMM_LIB=tune, MISPMM_STREAM="1"))
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    assert "row_stream cases ok: 12" in p.stdout
+
+
+def test_production_library_never_takes_the_persistent_launch():
+    """Measured and not adopted (profiles/r4/stream_ab.log): the production library does not carry the row_stream kernels and
+    multiplies every shape with the one-row-per-lane-group launch."""
+    csr = datasets.load_csr("n4c6-b13")
+    a = ops.DeviceCSR.from_host(csr, plan=False)
+    for n in (128, 256, 512):
+        ops.spmm_csr(a, dev(synth.dense_b(csr.num_cols, n)))
+        assert "row_gather" in capi.last_kernel(), (n, capi.last_kernel())
+
+
 # --------------------------------------------------------------------------- CSR
 CSR_CASES = [("Hamrle1", [1, 3, 32]), ("n3c5-b6", [8, 21]), ("qh1484", [64, 130]), ("delaunay_n12", [128]),
              ("GL7d25", [64, 100]), ("ACTIVSg10K", [128]), ("n4c6-b13", [128, 256, 512, 515])]

@@ -24,6 +24,8 @@ def main():
     p.add_argument("--acc", default="reference")
     p.add_argument("--launches", type=int, default=50)
     p.add_argument("--graph", action="store_true", help="replay a graph of back-to-back launches (steady state)")
+    p.add_argument("--sets", type=int, default=1, help="--graph: rotate over this many distinct (B, C) pairs (0 = 512 MiB of them): the "
+                                                       "HBM-streamed form of the loop (bench.py `hbm_streaming`)")
     a = p.parse_args()
     l = capi.lib()
     if not hasattr(l, "mispmm_debug_set_stamps"):
@@ -43,9 +45,12 @@ def main():
         sp = ctypes.c_void_p(stream.cuda_stream)
         ops.spmm_csr(da, b, out=c, acc=a.acc, stream=stream)
         torch.cuda.synchronize()
+        nsets = a.sets if a.sets > 0 else max(4, -(-(512 << 20) // ((csr.num_cols + csr.num_rows) * a.k_cols * 4)))
+        pairs = [(b, c)] + [(b.clone(), torch.empty_like(c)) for _ in range(nsets - 1)]
+        torch.cuda.synchronize()
         capi.check(l.mispmm_graph_begin(sp))
-        for _ in range(a.launches):
-            ops.spmm_csr(da, b, out=c, acc=a.acc, stream=stream)
+        for i in range(-(-a.launches // nsets) * nsets):
+            ops.spmm_csr(da, pairs[i % nsets][0], out=pairs[i % nsets][1], acc=a.acc, stream=stream)
         g = ctypes.c_void_p()
         capi.check(l.mispmm_graph_end(sp, ctypes.byref(g)))
         for _ in range(3):
