@@ -159,41 +159,131 @@ int mispmm_comm_destroy(mispmm_comm_t comm) {
     return MISPMM_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// What the three sharded entry points share: argument checks, then the slab exchange.  `row_bytes` / `ld_bytes` are the bytes
+// of one C row that carry values / from one row to the next (fp32 or bf16 C alike); slab d = C rows [bounds[d], bounds[d + 1]).
+struct Shards {
+    uint32_t ndev;
+    const int *devices;
+    const mispmm_stream_t *streams;
+    const uint32_t *bounds;       // in C rows
+    void *const *C;
+    size_t row_bytes, ld_bytes;
+    int gather_mode;
+    mispmm_comm_t comm;
+    bool equal_chunks = false, whole_chunks = false;
+    uint32_t M = 0, chunk = 0;
+};
+
+int check_shards(Shards &sh, const char *who) {
+    if (sh.ndev == 0) return fail(MISPMM_ERR_INVALID_ARG, "%s: no device", who);
+    if (!sh.devices || !sh.streams || !sh.bounds || !sh.C) return fail(MISPMM_ERR_INVALID_ARG, "%s: null argument array", who);
+    if (sh.gather_mode < MISPMM_GATHER_NONE || sh.gather_mode > MISPMM_GATHER_ALL_RCCL_EQUAL)
+        return fail(MISPMM_ERR_INVALID_ARG, "%s: unknown gather mode %d", who, sh.gather_mode);
+    if (sh.bounds[0] != 0) return fail(MISPMM_ERR_INVALID_ARG, "%s: rowBounds[0] must be 0", who);
+    for (uint32_t d = 0; d < sh.ndev; ++d) {
+        if (sh.bounds[d + 1] < sh.bounds[d]) return fail(MISPMM_ERR_INVALID_ARG, "%s: rowBounds must be non-decreasing", who);
+        if (!sh.C[d]) return fail(MISPMM_ERR_INVALID_ARG, "%s: C of device slot %u is null", who, d);
+    }
+    if (sh.ld_bytes < sh.row_bytes) return fail(MISPMM_ERR_INVALID_ARG, "%s: ldc smaller than N", who);
+    // equal chunks: slab d starts at row d * chunk, only the last may be short (its gather then reads and writes up to
+    // ndev * chunk rows of C: the EQUAL mode's contract says the caller allocated them)
+    sh.M = sh.bounds[sh.ndev];
+    sh.chunk = ceil_div(sh.M, sh.ndev);
+    sh.equal_chunks = true;
+    for (uint32_t d = 0; d < sh.ndev; ++d) sh.equal_chunks = sh.equal_chunks && sh.bounds[d] == std::min(sh.M, d * sh.chunk);
+    sh.whole_chunks = sh.equal_chunks && static_cast<uint64_t>(sh.chunk) * sh.ndev == sh.M;
+    if (sh.gather_mode == MISPMM_GATHER_ALL_RCCL || sh.gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL) {
+        if (!sh.comm || sh.comm->comms.size() != sh.ndev)
+            return fail(MISPMM_ERR_INVALID_ARG, "%s: RCCL gather needs a communicator over the same %u devices", who, sh.ndev);
+        for (uint32_t d = 0; d < sh.ndev; ++d)
+            if (sh.comm->devices[d] != sh.devices[d]) return fail(MISPMM_ERR_INVALID_ARG, "%s: communicator device order differs", who);
+        // a collective moves whole contiguous runs: with ldc > N it would carry the gap columns of every row from the
+        // owner into everybody's C
+        if (sh.ld_bytes != sh.row_bytes) return fail(MISPMM_ERR_UNSUPPORTED, "%s: the RCCL gathers need a dense C (ldc == N); use a peer gather", who);
+        if (sh.gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL && !sh.equal_chunks)
+            return fail(MISPMM_ERR_INVALID_ARG, "%s: GATHER_ALL_RCCL_EQUAL needs rowBounds[d] = d * ceil(M / ndev)", who);
+    }
+    return MISPMM_OK;
+}
+
+// exchange the slabs (stream order on the owner's stream: the copy follows the kernel that wrote the slab)
+int gather_slabs(const Shards &sh) {
+    if (sh.gather_mode == MISPMM_GATHER_NONE || sh.row_bytes == 0) return MISPMM_OK;
+    auto at = [&](uint32_t d, uint32_t row) { return static_cast<char *>(sh.C[d]) + static_cast<size_t>(row) * sh.ld_bytes; };
+    if (sh.gather_mode == MISPMM_GATHER_TO_FIRST || sh.gather_mode == MISPMM_GATHER_ALL_PEER) {
+        for (uint32_t d = 0; d < sh.ndev; ++d) {
+            const uint32_t r0 = sh.bounds[d], rows = sh.bounds[d + 1] - r0;
+            if (rows == 0) continue;
+            MISPMM_HIP_TRY(hipSetDevice(sh.devices[d]));
+            const uint32_t last = sh.gather_mode == MISPMM_GATHER_TO_FIRST ? 1u : sh.ndev;
+            for (uint32_t e = 0; e < last; ++e) {
+                if (e == d || sh.C[e] == sh.C[d]) continue;
+                if (sh.ld_bytes == sh.row_bytes) {  // dense C: the slab is one contiguous run
+                    MISPMM_HIP_TRY(hipMemcpyPeerAsync(at(e, r0), sh.devices[e], at(d, r0), sh.devices[d], static_cast<size_t>(rows) * sh.row_bytes,
+                                                      as_stream(sh.streams[d])));
+                } else {  // strided C: N columns of every row, the gap columns of the destination stay as they are
+                    MISPMM_HIP_TRY(hipMemcpy2DAsync(at(e, r0), sh.ld_bytes, at(d, r0), sh.ld_bytes, sh.row_bytes, rows, hipMemcpyDeviceToDevice,
+                                                    as_stream(sh.streams[d])));
+                }
+            }
+        }
+        return MISPMM_OK;
+    }
+    if (sh.equal_chunks && (sh.whole_chunks || sh.gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL)) {
+        // ONE in-place all-gather per device over equal slabs (device d's slab already sits at chunk d of its own C)
+        const size_t count = static_cast<size_t>(sh.chunk) * sh.row_bytes;
+        MISPMM_RCCL_TRY(rccl().GroupStart());
+        for (uint32_t d = 0; d < sh.ndev; ++d) {
+            const ncclResult_t r = rccl().AllGather(static_cast<char *>(sh.C[d]) + static_cast<size_t>(d) * count, sh.C[d], count, ncclInt8,
+                                                    sh.comm->comms[d], as_stream(sh.streams[d]));
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return fail(MISPMM_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString(r));
+            }
+        }
+        MISPMM_RCCL_TRY(rccl().GroupEnd());
+        return MISPMM_OK;
+    }
+    // uneven slabs (nnz-balanced row ranges): all-gather-v as grouped in-place broadcasts, one per slab
+    MISPMM_RCCL_TRY(rccl().GroupStart());
+    for (uint32_t root = 0; root < sh.ndev; ++root) {
+        const uint32_t r0 = sh.bounds[root], rows = sh.bounds[root + 1] - r0;
+        if (rows == 0) continue;
+        const size_t count = static_cast<size_t>(rows) * sh.row_bytes;
+        for (uint32_t d = 0; d < sh.ndev; ++d) {
+            const ncclResult_t r = rccl().Broadcast(at(d, r0), at(d, r0), count, ncclInt8, static_cast<int>(root), sh.comm->comms[d],
+                                                    as_stream(sh.streams[d]));
+            if (r != ncclSuccess) {
+                (void)rccl().GroupEnd();
+                return fail(MISPMM_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r));
+            }
+        }
+    }
+    MISPMM_RCCL_TRY(rccl().GroupEnd());
+    return MISPMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *rowBounds_host,
                          uint32_t K, const uint32_t *const *rowPtrs, const uint32_t *const *colIdxs,
                          const float *const *vals, const uint32_t *nnz_host, const uint32_t *uniformRowNnz_host,
                          const float *const *B, uint32_t N, uint32_t ldb, float *const *C, uint32_t ldc, int kernel,
                          int acc_mode, int gather_mode, mispmm_comm_t comm) {
-    if (ndev == 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: no device");
-    if (!devices || !streams || !rowBounds_host || !rowPtrs || !colIdxs || !vals || !nnz_host || !B || !C)
-        return fail(MISPMM_ERR_INVALID_ARG, "multi: null argument array");
-    if (gather_mode < MISPMM_GATHER_NONE || gather_mode > MISPMM_GATHER_ALL_RCCL_EQUAL)
-        return fail(MISPMM_ERR_INVALID_ARG, "multi: unknown gather mode %d", gather_mode);
-    if (rowBounds_host[0] != 0) return fail(MISPMM_ERR_INVALID_ARG, "multi: rowBounds[0] must be 0");
-    for (uint32_t d = 0; d < ndev; ++d) {
-        if (rowBounds_host[d + 1] < rowBounds_host[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: rowBounds must be non-decreasing");
-        if (!B[d] || !C[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: B or C of device slot %u is null", d);
-    }
-    if (ldc < N) return fail(MISPMM_ERR_INVALID_ARG, "multi: ldc smaller than N");
-    const bool rccl_mode = gather_mode == MISPMM_GATHER_ALL_RCCL || gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL;
-    // equal chunks: slab d starts at row d * chunk, only the last may be short (its gather then reads and writes up to
-    // ndev * chunk rows of C: the EQUAL mode's contract says the caller allocated them)
-    const uint32_t M = rowBounds_host[ndev], chunk = ceil_div(M, ndev);
-    bool equal_chunks = true;
-    for (uint32_t d = 0; d < ndev; ++d) equal_chunks = equal_chunks && rowBounds_host[d] == std::min(M, d * chunk);
-    const bool whole_chunks = equal_chunks && static_cast<uint64_t>(chunk) * ndev == M;
-    if (rccl_mode) {
-        if (!comm || comm->comms.size() != ndev) return fail(MISPMM_ERR_INVALID_ARG, "multi: RCCL gather needs a communicator over the same %u devices", ndev);
-        for (uint32_t d = 0; d < ndev; ++d)
-            if (comm->devices[d] != devices[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: communicator device order differs");
-        // a collective moves whole contiguous runs: with ldc > N it would carry the gap columns of every row from the
-        // owner into everybody's C
-        if (ldc != N) return fail(MISPMM_ERR_UNSUPPORTED, "multi: the RCCL gathers need a dense C (ldc == N, got ldc=%u N=%u); use a peer gather", ldc, N);
-        if (gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL && !equal_chunks)
-            return fail(MISPMM_ERR_INVALID_ARG, "multi: GATHER_ALL_RCCL_EQUAL needs rowBounds[d] = d * ceil(M / ndev)");
-    }
+    if (!rowPtrs || !colIdxs || !vals || !nnz_host || !B) return fail(MISPMM_ERR_INVALID_ARG, "multi: null argument array");
+    Shards sh{ndev, devices, streams, rowBounds_host, reinterpret_cast<void *const *>(C), static_cast<size_t>(N) * 4u, static_cast<size_t>(ldc) * 4u,
+              gather_mode, comm};
+    if (int st = check_shards(sh, "multi")) return st;
+    for (uint32_t d = 0; d < ndev; ++d)
+        if (!B[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi: B of device slot %u is null", d);
     DeviceGuard guard;
-    // 1. every device multiplies its row range into its own rows of its C
+    // every device multiplies its row range into its own rows of its C
     for (uint32_t d = 0; d < ndev; ++d) {
         const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
         if (rows == 0 || N == 0) continue;
@@ -208,60 +298,61 @@ int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_
                                 acc_mode);
         if (st != MISPMM_OK) return st;
     }
-    if (gather_mode == MISPMM_GATHER_NONE || N == 0) return MISPMM_OK;
-    // 2. exchange the slabs (stream order on the owner's stream: the copy follows the kernel that wrote the slab)
-    if (gather_mode == MISPMM_GATHER_TO_FIRST || gather_mode == MISPMM_GATHER_ALL_PEER) {
-        for (uint32_t d = 0; d < ndev; ++d) {
-            const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
-            if (rows == 0) continue;
-            const size_t off = static_cast<size_t>(r0) * ldc;
-            MISPMM_HIP_TRY(hipSetDevice(devices[d]));
-            const uint32_t last = gather_mode == MISPMM_GATHER_TO_FIRST ? 1u : ndev;
-            for (uint32_t e = 0; e < last; ++e) {
-                if (e == d || C[e] == C[d]) continue;
-                if (ldc == N) {  // dense C: the slab is one contiguous run
-                    MISPMM_HIP_TRY(hipMemcpyPeerAsync(C[e] + off, devices[e], C[d] + off, devices[d], static_cast<size_t>(rows) * N * sizeof(float),
-                                                      as_stream(streams[d])));
-                } else {  // strided C: N columns of every row, the gap columns of the destination stay as they are
-                    MISPMM_HIP_TRY(hipMemcpy2DAsync(C[e] + off, static_cast<size_t>(ldc) * sizeof(float), C[d] + off,
-                                                    static_cast<size_t>(ldc) * sizeof(float), static_cast<size_t>(N) * sizeof(float), rows,
-                                                    hipMemcpyDeviceToDevice, as_stream(streams[d])));
-                }
-            }
-        }
-        return MISPMM_OK;
+    return gather_slabs(sh);
+}
+
+// ELL sharded by rows ("ELL by rows"): device slot d holds rows [rowBounds[d], rowBounds[d + 1]) of the
+// ROW-MAJOR ELL (its own [rows x width] index and value arrays), a replica of B and a buffer for the full C.
+int mispmm_multi_ell_f32(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *rowBounds_host, uint32_t K,
+                         uint32_t width, const uint32_t *const *colIdxs, const float *const *vals, const float *const *B, uint32_t N,
+                         uint32_t ldb, float *const *C, uint32_t ldc, int kernel, int acc_mode, int gather_mode, mispmm_comm_t comm) {
+    if (!colIdxs || !vals || !B) return fail(MISPMM_ERR_INVALID_ARG, "multi_ell: null argument array");
+    Shards sh{ndev, devices, streams, rowBounds_host, reinterpret_cast<void *const *>(C), static_cast<size_t>(N) * 4u, static_cast<size_t>(ldc) * 4u,
+              gather_mode, comm};
+    if (int st = check_shards(sh, "multi_ell")) return st;
+    for (uint32_t d = 0; d < ndev; ++d)
+        if (!B[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi_ell: B of device slot %u is null", d);
+    DeviceGuard guard;
+    for (uint32_t d = 0; d < ndev; ++d) {
+        const uint32_t r0 = rowBounds_host[d], rows = rowBounds_host[d + 1] - r0;
+        if (rows == 0 || N == 0) continue;
+        MISPMM_HIP_TRY(hipSetDevice(devices[d]));
+        const int st = mispmm_ell_f32(streams[d], rows, K, width, colIdxs[d], vals[d], B[d], N, ldb, C[d] + static_cast<size_t>(r0) * ldc, ldc, kernel,
+                                      acc_mode);
+        if (st != MISPMM_OK) return st;
     }
-    if (equal_chunks && (whole_chunks || gather_mode == MISPMM_GATHER_ALL_RCCL_EQUAL)) {
-        // ONE in-place all-gather per device over equal slabs (device d's slab already sits at chunk d of its own C)
-        const size_t count = static_cast<size_t>(chunk) * N;
-        MISPMM_RCCL_TRY(rccl().GroupStart());
-        for (uint32_t d = 0; d < ndev; ++d) {
-            const ncclResult_t r = rccl().AllGather(C[d] + static_cast<size_t>(d) * count, C[d], count, ncclFloat, comm->comms[d], as_stream(streams[d]));
-            if (r != ncclSuccess) {
-                (void)rccl().GroupEnd();
-                return fail(MISPMM_ERR_HIP, "ncclAllGather failed: %s", rccl().GetErrorString(r));
-            }
-        }
-        MISPMM_RCCL_TRY(rccl().GroupEnd());
-        return MISPMM_OK;
+    return gather_slabs(sh);
+}
+
+// BSR sharded by BLOCK rows ("BSR shards by block-rows"), in the layout of BASELINE config 4: device
+// slot d holds block rows [blockRowBounds[d], blockRowBounds[d + 1]) as column-compacted bf16 block rows in fixed step slots
+// (its own mispmm_bsr_compact_slots_bf16_host output), a replica of the bf16 B and a buffer for the full C (fp32 or bf16).
+int mispmm_multi_bsrc_slots_bf16(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *blockRowBounds_host,
+                                 uint32_t K, const uint32_t *nSteps_host, const uint32_t *const *extraPtrs, const uint32_t *const *cols,
+                                 const uint16_t *const *tiles, const uint16_t *const *B, uint32_t N, uint32_t ldb, void *const *C, uint32_t ldc,
+                                 int c_bf16, int gather_mode, mispmm_comm_t comm) {
+    if (!nSteps_host || !extraPtrs || !cols || !tiles || !B || !blockRowBounds_host) return fail(MISPMM_ERR_INVALID_ARG, "multi_bsrc: null argument array");
+    if (ndev == 0 || ndev > 64) return fail(MISPMM_ERR_INVALID_ARG, "multi_bsrc: 1 .. 64 device slots");
+    const size_t esz = c_bf16 ? 2u : 4u;
+    uint32_t rows[65];                                          // the slabs in C ROWS: 16 per block row
+    for (uint32_t d = 0; d <= ndev; ++d) {
+        if (static_cast<uint64_t>(blockRowBounds_host[d]) * 16u > 0xFFFFFFFFull) return fail(MISPMM_ERR_INVALID_ARG, "multi_bsrc: more than 2^32 rows");
+        rows[d] = blockRowBounds_host[d] * 16u;
     }
-    // uneven slabs (nnz-balanced row ranges): all-gather-v as grouped in-place broadcasts, one per slab
-    MISPMM_RCCL_TRY(rccl().GroupStart());
-    for (uint32_t root = 0; root < ndev; ++root) {
-        const uint32_t r0 = rowBounds_host[root], rows = rowBounds_host[root + 1] - r0;
-        if (rows == 0) continue;
-        const size_t off = static_cast<size_t>(r0) * ldc, count = static_cast<size_t>(rows) * N;
-        for (uint32_t d = 0; d < ndev; ++d) {
-            const ncclResult_t r = rccl().Broadcast(C[d] + off, C[d] + off, count, ncclFloat, static_cast<int>(root), comm->comms[d],
-                                                    as_stream(streams[d]));
-            if (r != ncclSuccess) {
-                (void)rccl().GroupEnd();
-                return fail(MISPMM_ERR_HIP, "ncclBroadcast failed: %s", rccl().GetErrorString(r));
-            }
-        }
+    Shards sh{ndev, devices, streams, rows, C, static_cast<size_t>(N) * esz, static_cast<size_t>(ldc) * esz, gather_mode, comm};
+    if (int st = check_shards(sh, "multi_bsrc")) return st;
+    for (uint32_t d = 0; d < ndev; ++d)
+        if (!B[d]) return fail(MISPMM_ERR_INVALID_ARG, "multi_bsrc: B of device slot %u is null", d);
+    DeviceGuard guard;
+    for (uint32_t d = 0; d < ndev; ++d) {
+        const uint32_t br0 = blockRowBounds_host[d], brows = blockRowBounds_host[d + 1] - br0;
+        if (brows == 0 || N == 0) continue;
+        MISPMM_HIP_TRY(hipSetDevice(devices[d]));
+        void *slab = static_cast<char *>(C[d]) + static_cast<size_t>(br0) * 16u * ldc * esz;
+        const int st = mispmm_bsrc_slots_bf16(streams[d], brows, K, nSteps_host[d], extraPtrs[d], cols[d], tiles[d], B[d], N, ldb, slab, ldc, c_bf16);
+        if (st != MISPMM_OK) return st;
     }
-    MISPMM_RCCL_TRY(rccl().GroupEnd());
-    return MISPMM_OK;
+    return gather_slabs(sh);
 }
 
 }  // extern "C"

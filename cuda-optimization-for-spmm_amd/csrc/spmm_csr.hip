@@ -833,3 +833,88 @@ extern "C" int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t 
     }
     return MISPMM_OK;
 }
+
+// ---- autotune: plan order or storage order, measured once per (matrix, N) -------------------------------------------------
+extern "C" int mispmm_autotune_pick(const float *times_us, uint32_t n, float min_gain) {
+    if (!times_us || n == 0) return -1;
+    auto usable = [](float t) { return t > 0.f && t < 3.0e38f && t == t; };
+    int best = usable(times_us[0]) ? 0 : -1;
+    for (uint32_t i = 1; i < n; ++i) {
+        if (!usable(times_us[i])) continue;
+        if (best < 0) best = static_cast<int>(i);
+        else if (best == 0 ? times_us[i] < times_us[0] * (1.f - min_gain) : times_us[i] < times_us[best]) best = static_cast<int>(i);
+    }
+    return best < 0 ? 0 : best;
+}
+
+extern "C" int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                            const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, const uint32_t *planRowPtrs,
+                                            const uint32_t *planColIdxs, const float *planVals, const uint32_t *planRowMap, uint32_t N,
+                                            int acc_mode, uint32_t launches, int *use_plan_out, float *times_us_out) {
+    if (!use_plan_out) return fail(MISPMM_ERR_INVALID_ARG, "autotune: use_plan_out is null");
+    *use_plan_out = 0;
+    const float inf = __builtin_huge_valf();
+    float times[2] = {inf, inf};
+    if (times_us_out) times_us_out[0] = times_us_out[1] = inf;
+    if (M == 0 || N == 0 || nnz == 0 || !planRowMap || !planColIdxs || !planVals) return MISPMM_OK;   // nothing to choose from
+    if (launches == 0) launches = 32;
+    hipStream_t st = as_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(MISPMM_ERR_INVALID_ARG, "autotune: the stream is being captured");
+    float *B = nullptr, *C = nullptr;
+    const size_t b_elems = static_cast<size_t>(K) * N, c_elems = static_cast<size_t>(M) * N;
+    MISPMM_HIP_TRY(hipMalloc(&B, b_elems * sizeof(float)));
+    if (hipMalloc(&C, c_elems * sizeof(float)) != hipSuccess) {
+        (void)hipFree(B);
+        return fail(MISPMM_ERR_ALLOC, "autotune: no memory for the scratch C (%zu bytes)", c_elems * sizeof(float));
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int status = MISPMM_OK;
+    auto cleanup = [&] {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(B);
+        (void)hipFree(C);
+    };
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(B), 0x3F800000, b_elems, st) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess) {
+        cleanup();
+        return fail(MISPMM_ERR_HIP, "autotune: scratch setup failed");
+    }
+    const float *bl[1] = {B};
+    float *cl[1] = {C};
+    auto run = [&](int which) -> int {
+        if (which == 1)
+            return mispmm_csr_plan_f32(stream, M, K, nnz, planRowPtrs, planColIdxs, planVals, uniformRowNnz, planRowMap, 1, bl, N, N, cl, N, acc_mode);
+        if (uniformRowNnz && static_cast<uint64_t>(K) * N * 4u <= 0x7FFFFFFFull)
+            return mispmm_csr_uniform_f32(stream, M, K, uniformRowNnz, colIdxs, vals, B, N, N, C, N, acc_mode);
+        return mispmm_csr_f32(stream, M, K, nnz, rowPtrs, colIdxs, vals, B, N, N, C, N, MISPMM_KERNEL_AUTO, acc_mode);
+    };
+    for (int which = 0; which < 2 && status == MISPMM_OK; ++which) {
+        int rs = MISPMM_OK;
+        for (int i = 0; i < 3 && rs == MISPMM_OK; ++i) rs = run(which);               // warm: code, caches, clocks
+        if (rs == MISPMM_ERR_UNSUPPORTED) continue;                                   // this candidate does not take the shape
+        if (rs != MISPMM_OK) { status = rs; break; }
+        float best = inf;
+        for (int round = 0; round < 2; ++round) {
+            (void)hipEventRecord(e0, st);
+            for (uint32_t i = 0; i < launches && rs == MISPMM_OK; ++i) rs = run(which);
+            (void)hipEventRecord(e1, st);
+            if (rs != MISPMM_OK || hipEventSynchronize(e1) != hipSuccess) { status = rs != MISPMM_OK ? rs : MISPMM_ERR_HIP; break; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) best = std::min(best, ms * 1e3f / static_cast<float>(launches));
+        }
+        times[which] = best;
+    }
+    (void)hipStreamSynchronize(st);
+    cleanup();
+    if (status != MISPMM_OK) return status;
+    if (times_us_out) {
+        times_us_out[0] = times[0];
+        times_us_out[1] = times[1];
+    }
+    *use_plan_out = mispmm_autotune_pick(times, 2, 0.02f) == 1;
+    return MISPMM_OK;
+}
+

@@ -3,6 +3,7 @@
 // written against those classes compiles here; storage comes from the C ABI (pinned host or device
 // memory, zero-filled), index type MT = uint32_t, value type DT = float or double.
 #pragma once
+#include <map>
 
 #include "formats/dense.hpp"
 
@@ -46,6 +47,10 @@ template <typename _dataT, typename _metaT> class SparseMatrixCSR : public Spars
     MT *planColIdxs = nullptr;
     _dataT *planData = nullptr;
     MT *planRowMap = nullptr;
+    // plan order or storage order for a dense operand of N columns: measured on the first product of that width
+    // (mispmm_csr_autotune_plan_f32 on scratch operands, outside every timed region) and remembered here; key = N * 2 + (FAST ? 1 : 0)
+    std::map<uint64_t, bool> planChoice;
+    bool usePlanFor(uint32_t N, int accMode);
 
     SparseMatrixCSR() = default;
     explicit SparseMatrixCSR(std::string filePath);

@@ -118,6 +118,29 @@ template <typename DT, typename MT> SparseMatrixCSR<DT, MT> *SparseMatrixCSR<DT,
     return d;
 }
 
+// Plan order or storage order for a dense operand of N columns?  Measured once per width on scratch operands
+// (mispmm_csr_autotune_plan_f32) and remembered; where nothing can be measured (no plan, not a float matrix, the call fails)
+// the footprint rule of round 3: plan where the slice of B one XCD reads does not fit its 4 MiB L2.
+template <typename DT, typename MT> bool SparseMatrixCSR<DT, MT>::usePlanFor(uint32_t N, int accMode) {
+    if (!this->planRowMap || !this->onDevice) return false;
+    const bool rule = N % 512 == 0 && (uint64_t)this->numCols * (N / 8) * 4 > (4ull << 20);
+    if constexpr (!std::is_same_v<DT, float>) {
+        return rule;
+    } else {
+        const uint64_t key = (uint64_t)N * 2 + (accMode == MISPMM_ACC_FAST ? 1 : 0);
+        auto it = planChoice.find(key);
+        if (it != planChoice.end()) return it->second;
+        int use = 0;
+        float times[2];
+        const int st = mispmm_csr_autotune_plan_f32(nullptr, this->numRows, this->numCols, this->numNonZero, this->rowPtrs, this->colIdxs, this->data,
+                                                    this->uniformRowNnz, this->planRowPtrs, this->planColIdxs, this->planData, this->planRowMap, N,
+                                                    accMode, 0, &use, times);
+        if (st != MISPMM_OK) return rule;
+        planChoice[key] = use != 0;
+        return use != 0;
+    }
+}
+
 template <typename DT, typename MT> DenseMatrix<DT, MT> *SparseMatrixCSR<DT, MT>::toDense() {
     assert(!this->onDevice);
     auto *dm = new DenseMatrix<DT, MT>(this->numRows, this->numCols, false);

@@ -44,12 +44,12 @@ DenseMatrix<DT, MT> *spmmCSRWrapper(int kernelNum, SparseMatrixCSR<DT, MT> *a, D
         const WrapperShape shape{"CSR", a->numRows, a->numCols, a->numNonZero, 2.0 * a->numNonZero * n,
                                  a->numNonZero * 8.0 + (a->numRows + 1.0) * 4 + a->numCols * n * 4 + a->numRows * n * 4};
         const int acc = accModeOf<AccT>();
+        // rows in the clustered order copy2Device found, where that is FASTER for this width -- measured once per width on scratch
+        // operands, before the timed region (round 3 had a footprint rule here: n4c6-b13 x K=512 13.60 -> 12.99 us with the plan,
+        // K=128 3.47 -> 3.69; the rule missed ACTIVSg10K x K=256: 12.6 -> 11.1).  Same bits: every row keeps its entries in storage order.
+        const bool planPays = (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5) && a->usePlanFor(b->numCols, acc);
         return runWrapper<DT, MT>(shape, kernelNum, b, ref, [&](float *c, uint32_t ldc, mispmm_stream_t stream) {
-            // rows in the clustered order copy2Device found, where the slice of B one XCD reads (every B row x its column part
-            // of N / 8 columns) does not fit the 4 MiB L2 -- measured in one process on one set of operands: n4c6-b13 x K=512 13.60 -> 12.99 us,
-            // K=128 3.47 -> 3.69, K=256 5.75 -> 6.51 (profiles/r3/plan_order.log).  Same bits: every row keeps its entries in storage order.
-            const bool planPays = b->numCols % 512 == 0 && (uint64_t)a->numCols * (b->numCols / 8) * 4 > (4ull << 20);
-            if (a->planRowMap && planPays && (kernelNum == MISPMM_KERNEL_AUTO || kernelNum == 5)) {
+            if (a->planRowMap && planPays) {
                 const float *bl[1] = {b->data};
                 float *cl[1] = {c};
                 const int st = mispmm_csr_plan_f32(stream, a->numRows, a->numCols, a->numNonZero, a->planRowPtrs, a->planColIdxs,
@@ -101,9 +101,9 @@ bool spmmCSRBatched(int batch, SparseMatrixCSR<DT, MT> *a, DenseMatrix<DT, MT> *
             bs[i] = allocateBuffer<float>((size_t)K * N, true);
             copyBuffer(bs[i], true, b->data, true, (size_t)K * N * sizeof(float));
         }
+        const bool planPays = a->usePlanFor(N, acc);   // measured once per width, outside the timed regions
         const auto t1 = clock::now();
         for (int i = 0; i < batch; ++i) cs[i] = allocateBuffer<float>((size_t)M * N, true);  // prolog: zero-filled results
-        const bool planPays = N % 512 == 0 && (uint64_t)K * (N / 8) * 4 > (4ull << 20);
         auto launch = [&](mispmm_stream_t stream) {
             if (a->planRowMap && planPays) {
                 const int st = mispmm_csr_plan_f32(stream, M, K, a->numNonZero, a->planRowPtrs, a->planColIdxs, a->planData,

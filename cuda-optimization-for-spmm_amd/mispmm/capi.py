@@ -55,6 +55,9 @@ SIGNATURES = {
     "mispmm_csr_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i, _i]),
     "mispmm_csr_uniform_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_batch_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _pvp, _u32, _u32, _pvp, _u32, _i]),
+    "mispmm_csr_autotune_plan_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _i, _u32, _c.POINTER(_i),
+                                          _c.POINTER(_c.c_float)]),
+    "mispmm_autotune_pick": (_i, [_c.POINTER(_c.c_float), _u32, _c.c_float]),
     "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32), _vp]),
     "mispmm_csr_hybrid_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
@@ -90,6 +93,10 @@ SIGNATURES = {
     "mispmm_comm_destroy": (_i, [_vp]),
     "mispmm_multi_csr_f32": (_i, [_u32, _c.POINTER(_i), _pvp, _c.POINTER(_u32), _u32, _pvp, _pvp, _pvp, _c.POINTER(_u32),
                                   _c.POINTER(_u32), _pvp, _u32, _u32, _pvp, _u32, _i, _i, _i, _vp]),
+    "mispmm_multi_ell_f32": (_i, [_u32, _c.POINTER(_i), _pvp, _c.POINTER(_u32), _u32, _u32, _pvp, _pvp, _pvp, _u32, _u32, _pvp, _u32,
+                                  _i, _i, _i, _vp]),
+    "mispmm_multi_bsrc_slots_bf16": (_i, [_u32, _c.POINTER(_i), _pvp, _c.POINTER(_u32), _u32, _c.POINTER(_u32), _pvp, _pvp, _pvp, _pvp,
+                                          _u32, _u32, _pvp, _u32, _i, _i, _vp]),
     "mispmm_slab_scatter": (_i, [_vp, _vp, _sz, _pvp, _u32]),
 }
 
@@ -109,6 +116,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 f"{LIB_PATH} is not built -- run `make -C {PKG_DIR}`; mispmm has no CPU fallback")
+        # The PyTorch wheel ships a HIP runtime of its own (torch/lib/libamdhip64.so); libmispmm.so links the system one
+        # (/opt/rocm/lib/libamdhip64.so.7).  Same soname: whichever is loaded first serves both.  Loaded in THIS order --
+        # torch, then the library -- both use torch's runtime and share its device context; the other way round torch finds
+        # "no ROCm-capable device" (seen with `python __graft_entry__.py smoke`, whose build() loads the library first).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the export is missing

@@ -3,7 +3,7 @@ streams to the C ABI (data_ptr() in, data_ptr() out).  PyTorch is used for
 allocation and stream handles only -- all arithmetic happens in libmispmm.so."""
 import ctypes
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
@@ -139,10 +139,42 @@ L2_BYTES = 4 << 20
 
 
 def plan_pays(num_cols, n):
-    """True where the B slice one XCD reads (num_cols rows x its column part of n / 8 columns, fp32) exceeds the L2."""
+    """The footprint RULE (the prior, used when the choice cannot be measured): True where the B slice one XCD reads (num_cols
+    rows x its column part of n / 8 columns, fp32) exceeds the L2."""
     if PLAN_MIN_N is not None:
         return n >= PLAN_MIN_N
     return n % 512 == 0 and num_cols * (n // 8) * 4 > L2_BYTES
+
+
+AUTOTUNE = os.environ.get("MISPMM_AUTOTUNE", "1") != "0"   # MISPMM_AUTOTUNE=0: the footprint rule alone (measurement aid)
+
+
+def autotune_pick(times_us, min_gain=0.02):
+    """mispmm_autotune_pick: index of the candidate to take given its timings -- a pure function (candidate 0 = the default
+    is kept unless another is at least min_gain faster)."""
+    arr = (ctypes.c_float * len(times_us))(*[float(t) for t in times_us])
+    return int(capi.lib().mispmm_autotune_pick(arr, len(times_us), ctypes.c_float(min_gain)))
+
+
+def use_plan(a, n, acc="reference", stream=None):
+    """Plan order or storage order for a product of `a` with a dense operand of n columns: MEASURED on the first product of that
+    width (mispmm_csr_autotune_plan_f32: both candidates timed on scratch operands, ~1-2 ms) and remembered in a.tuned; the
+    footprint rule where it cannot be measured (stream being captured, autotune switched off, MISPMM_PLAN_MIN_N given)."""
+    if a.plan is None:
+        return False
+    if PLAN_MIN_N is not None or not AUTOTUNE:
+        return plan_pays(a.num_cols, n)
+    key = (int(n), acc)
+    if key not in a.tuned:
+        p = a.plan
+        use, times = ctypes.c_int(0), (ctypes.c_float * 2)()
+        st = capi.lib().mispmm_csr_autotune_plan_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.nnz, _p(a.row_ptrs), _p(a.col_idxs), _p(a.data),
+                                                     a.uniform_row_nnz, _p(p.row_ptrs), _p(p.col_idxs), _p(p.data), _p(p.row_map), int(n),
+                                                     capi.ACC_MODES[acc], 0, ctypes.byref(use), times)
+        if st != capi.OK:                       # e.g. the stream is being captured: nothing measured, nothing remembered
+            return plan_pays(a.num_cols, n)
+        a.tuned[key] = (bool(use.value), (float(times[0]), float(times[1])))
+    return a.tuned[key][0]
 
 
 @dataclass
@@ -158,6 +190,7 @@ class DeviceCSR:
     plan: CsrPlan = None         # rows in a clustered order, kept when the clustering cuts the B rows an XCD must fetch
     long_spans: int = 0          # leading positions of `spans` that hold the long rows (the split body of the two-body launch)
     spans_hybrid_only: bool = False   # short rows on average: the list is for the two-body launch only, never the split kernel
+    tuned: dict = field(default_factory=dict)   # (n, acc) -> (use the plan?, (storage-order us, plan-order us)) as measured by use_plan
 
     @staticmethod
     def from_host(csr, device="cuda", spans=None, share_len=0, plan=None):
@@ -311,7 +344,7 @@ def spmm_csr(a, b, out=None, kernel=0, acc="reference", stream=None, use_hint=Tr
     n = b.shape[1]
     c = _out(a.num_rows, n, b, out)
     hints = use_hint and os.environ.get("MISPMM_NO_HINT") != "1"
-    if hints and a.plan is not None and int(kernel) in (0, 5) and plan_pays(a.num_cols, n):
+    if hints and a.plan is not None and int(kernel) in (0, 5) and use_plan(a, n, acc, stream):
         # rows in the clustered order of the plan (same bits: every row keeps its entries in storage order)
         if _csr_plan(a, [b], [c], acc, stream):
             return c
@@ -383,7 +416,7 @@ def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
         for b, c in zip(bs, outs):
             spmm_csr(a, b, out=c, acc=acc, stream=stream)
         return outs
-    if a.plan is not None and os.environ.get("MISPMM_NO_HINT") != "1" and plan_pays(a.num_cols, n):
+    if a.plan is not None and os.environ.get("MISPMM_NO_HINT") != "1" and use_plan(a, n, acc, stream):
         if _csr_plan(a, bs, outs, acc, stream):
             return outs
     blist = (ctypes.c_void_p * len(bs))(*[b.data_ptr() for b in bs])

@@ -213,6 +213,24 @@ int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t
                         uint32_t batch, const float *const *B_list_host, uint32_t N, uint32_t ldb, float *const *C_list_host,
                         uint32_t ldc, int acc_mode);
 
+/* Autotune (round 4): whether a product of THIS matrix with a dense operand of N columns is faster from the plan-order arrays
+ * or from the storage-order ones is MEASURED, once per (matrix, N), instead of guessed from a footprint rule (the rule the
+ * measurements of round 3 gave -- plan where the B slice of an XCD exceeds its L2 -- misses e.g. ACTIVSg10K x N = 256:
+ * 12.6 -> 11.1 us with the plan).  Scratch B (ones) and C are allocated, each candidate is warmed and then timed over 2 rounds
+ * of `launches` back-to-back launches between HIP events on `stream` (0 = 32), the scratch is freed; times_us_out[0] = storage
+ * order (mispmm_csr_uniform_f32 / mispmm_csr_f32 kernel auto), [1] = plan order, a candidate the shape does not support = +inf.
+ * *use_plan_out = mispmm_autotune_pick(times, 2, 0.02) == 1.  Synchronises `stream`; never call it while the stream is being
+ * captured.  The format objects (SparseMatrixCSR::copy2Device's caller, DeviceCSR) call it on the first product of a width and
+ * remember the answer.  New capability: the reference's only shape rule is K4's shared-memory guard (spmm_csr_k4.cu:97-101).
+ *   mispmm_autotune_pick   the decision alone, a pure function of the timings (so that it can be tested without a GPU): the
+ *                          index of the smallest time, except that candidate 0 (the default) is kept unless another is at
+ *                          least `min_gain` (e.g. 0.02 = 2 %) faster; non-finite / non-positive times never win; -1 if n = 0. */
+int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t nnz, const uint32_t *rowPtrs,
+                                 const uint32_t *colIdxs, const float *vals, uint32_t uniformRowNnz, const uint32_t *planRowPtrs,
+                                 const uint32_t *planColIdxs, const float *planVals, const uint32_t *planRowMap, uint32_t N,
+                                 int acc_mode, uint32_t launches, int *use_plan_out, float *times_us_out);
+int mispmm_autotune_pick(const float *times_us, uint32_t n, float min_gain);
+
 /* Several products with the same A in ONE launch: C_list[i] = A * B_list[i], i < batch (HOST arrays of device
  * pointers; every operand N columns wide with leading dimensions ldb / ldc).  Same arithmetic and results as
  * `batch` calls of mispmm_csr_f32 (kernel 5) / mispmm_csr_uniform_f32 (uniformRowNnz > 0: rowPtrs may be NULL),
@@ -447,6 +465,21 @@ int mispmm_multi_csr_f32(uint32_t ndev, const int *devices, const mispmm_stream_
                          const float *const *vals, const uint32_t *nnz_host, const uint32_t *uniformRowNnz_host,
                          const float *const *B, uint32_t N, uint32_t ldb, float *const *C, uint32_t ldc, int kernel,
                          int acc_mode, int gather_mode, mispmm_comm_t comm);
+/* The same sharding for the other two formats SURVEY.md section 8(e) names ("BSR shards by block-rows; ELL by rows"; the
+ * reference has no sharded counterpart of src/spmm/ell/spmm_ell_k1.cu:10-35 or src/spmm/bsr/spmm_bsr_k1.cu:9-41).  Same contract
+ * as mispmm_multi_csr_f32: host arrays of device pointers, per-device streams, every gather mode, strided C through the peer
+ * gathers only.
+ *   ELL: device slot d holds rows [rowBounds[d], rowBounds[d+1]) of the ROW-MAJOR ELL ([rows x width] colIdxs / vals of its own).
+ *   BSR (BASELINE config 4's layout): device slot d holds BLOCK rows [blockRowBounds[d], blockRowBounds[d+1]) as column-compacted
+ *   bf16 block rows in fixed step slots -- mispmm_bsr_compact_slots_bf16_host run on ITS block rows (nSteps_host[d], extraPtrs[d],
+ *   cols[d], tiles[d]) --, a replica of the bf16 B and the full C (fp32, or bf16 with c_bf16 = 1); at most 64 slots. */
+int mispmm_multi_ell_f32(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *rowBounds_host, uint32_t K,
+                         uint32_t width, const uint32_t *const *colIdxs, const float *const *vals, const float *const *B, uint32_t N,
+                         uint32_t ldb, float *const *C, uint32_t ldc, int kernel, int acc_mode, int gather_mode, mispmm_comm_t comm);
+int mispmm_multi_bsrc_slots_bf16(uint32_t ndev, const int *devices, const mispmm_stream_t *streams, const uint32_t *blockRowBounds_host,
+                                 uint32_t K, const uint32_t *nSteps_host, const uint32_t *const *extraPtrs, const uint32_t *const *cols,
+                                 const uint16_t *const *tiles, const uint16_t *const *B, uint32_t N, uint32_t ldb, void *const *C, uint32_t ldc,
+                                 int c_bf16, int gather_mode, mispmm_comm_t comm);
 /* One launch copies `bytes` (a multiple of 16; 16-byte aligned pointers) from src to each of ndst <= 16
  * destinations, which may be another device's memory mapped into this process (peer access, or an IPC handle
  * opened by a one-process-per-GPU host: mispmm/dist.py).  Enqueue only; capturable into a graph. */

@@ -97,6 +97,78 @@ def test_rccl_gather_takes_one_allgather_over_equal_slabs(oracle):
     job.close()
 
 
+def test_ell_sharded_by_rows(oracle):
+    """mispmm_multi_ell_f32 ("ELL by rows"): the row-major ELL of n4c6-b13 (config 3's operand) and a
+    ragged one with padding, cut over 1 / 2 / 3 device slots of the one card -- every slot's rows and every gathered C equal
+    the oracle's ELL product bit for bit; strided C keeps its gap columns through the peer gathers."""
+    from mispmm import formats
+    from mispmm.multi import MultiEllSpmm
+    for name, n in (("n4c6-b13", 256), ("qh1484", 40)):
+        csr = datasets.load_csr(name)
+        ell = formats.csr_to_ell_colmajor(csr)
+        b = synth.dense_b(csr.num_cols, n)
+        ref = oracle.spmm_ell_colmajor(ell.num_rows, ell.row_idxs, ell.data, b)
+        for devices, gathers in (([0], ["none", "first", "rccl"]), ([0, 0], ["first", "peer"]), ([0, 0, 0], ["peer"])):
+            for gather in gathers:
+                job = MultiEllSpmm(ell, n, devices, gather=gather)
+                job.set_b(b)
+                for _ in range(2):
+                    job.step()
+                job.sync()
+                assert np.array_equal(job.sharded_c(), ref), (name, devices, gather)
+                if gather != "none":
+                    assert np.array_equal(job.full_c(0).cpu().numpy(), ref), (name, devices, gather)
+                if gather in ("peer", "rccl"):
+                    for slot in range(len(devices)):
+                        assert np.array_equal(job.full_c(slot).cpu().numpy(), ref), (name, devices, gather, slot)
+                job.close()
+    job = MultiEllSpmm(ell, 40, [0, 0], gather="peer", ldc=48)
+    for c in job.c:
+        c.fill_(-9.0)
+    job.set_b(b)
+    job.step()
+    job.sync()
+    for c in job.c:
+        assert np.array_equal(c[:, :40].cpu().numpy(), ref) and bool((c[:, 40:] == -9.0).all())
+    job.close()
+
+
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_bf16_block_rows_sharded_by_block_rows(oracle, out_bf16):
+    """mispmm_multi_bsrc_slots_bf16 ("BSR shards by block-rows"; BASELINE config 4's kernel on every
+    shard): ACTIVSg10K BSR-16 x K=128 over 1 / 2 / 3 slots -- the sharded C equals the UNSHARDED kernel's C bit for bit (block
+    rows are independent and a shard's compaction lists the same columns per block row) and the oracle within the bf16 bound."""
+    from mispmm import formats
+    from mispmm.multi import MultiBsrcSlotsSpmm
+    csr = datasets.load_csr("ACTIVSg10K")
+    bsr = formats.csr_to_bsr(csr, 16)
+    n = 128
+    b = synth.dense_b(csr.num_cols, n)
+    whole = ops.spmm_bsrc_slots_bf16(ops.DeviceBSRCSlots.from_host(bsr), ops.f32_to_bf16(dev(b)), out_bf16=out_bf16)
+    torch.cuda.synchronize()
+    a16 = synth.bf16_round(bsr.data.reshape(-1)).reshape(bsr.data.shape)
+    b16 = synth.bf16_round(b.reshape(-1)).reshape(b.shape)
+    ref = oracle.spmm_bsr(bsr.num_rows, 16, 16, bsr.block_row_ptrs, bsr.block_col_idxs, a16, b16)
+    scale = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, np.abs(synth.bf16_round(csr.data)), np.abs(b16)).astype(np.float64)
+    f32 = lambda t: (ops.bf16_to_f32(t) if out_bf16 else t).cpu().numpy()  # noqa: E731
+    slack = (2 ** -8 * np.abs(ref) if out_bf16 else 0.0) + 2e-6 * scale + 1e-30
+    assert np.all(np.abs(f32(whole) - ref) <= slack)
+    for devices, gathers in (([0], ["none", "first", "rccl"]), ([0, 0], ["first", "peer"]), ([0, 0, 0], ["peer"])):
+        for gather in gathers:
+            job = MultiBsrcSlotsSpmm(bsr, n, devices, gather=gather, out_bf16=out_bf16)
+            assert int(job.block_bounds[-1]) == bsr.num_block_rows
+            job.set_b(b)
+            job.step()
+            job.sync()
+            assert np.array_equal(job.sharded_c(), whole.cpu().numpy()), (devices, gather)
+            if gather != "none":
+                assert torch.equal(job.full_c(0), whole), (devices, gather)
+            if gather in ("peer", "rccl"):
+                for slot in range(len(devices)):
+                    assert torch.equal(job.full_c(slot), whole), (devices, gather, slot)
+            job.close()
+
+
 def test_slab_scatter_copies_to_every_destination():
     import ctypes
     src = torch.arange(4096 * 3 + 4, dtype=torch.float32, device="cuda")

@@ -859,10 +859,49 @@ def test_csr_plan_order_is_bit_exact(oracle, name, n, taken):
         assert_fast_close(fast.cpu().numpy(), ref, abs_scale(csr, b))
     else:
         assert np.all(cw.cpu().numpy() == -7.0)                      # declined before anything was launched
-    # the public entry point takes the plan where the B slice of an XCD exceeds its L2 and gives the same bits either way
+    # the public entry point MEASURES plan order against storage order on the first product of a width, remembers the answer,
+    # takes what it measured -- and gives the same bits either way.  The decision is a pure function of the two timings.
     assert np.array_equal(ops.spmm_csr(a, bd).cpu().numpy(), ref)
-    assert ("plan-order" in capi.last_kernel()) == (taken and ops.plan_pays(csr.num_cols, n))
+    tag = capi.last_kernel()
+    use, times = a.tuned[(n, "reference")]
+    assert ("plan-order" in tag) == use and use == (ops.autotune_pick(times) == 1)
+    assert use or not taken or times[1] >= times[0] * 0.98           # the plan is dropped only when it is not 2 % faster
+    if not taken:
+        assert not use and times[1] == float("inf")                  # a shape the plan launch declines can never be chosen
+    ops.spmm_csr(a, bd)
+    assert capi.last_kernel() == tag and len(a.tuned) == 1           # measured once
+    # the footprint rule stays as the prior where nothing can be measured (a stream being captured, MISPMM_AUTOTUNE=0)
     assert ops.plan_pays(25605, 512) and not ops.plan_pays(25605, 256) and not ops.plan_pays(4096, 512)
+
+
+def test_autotune_decision_is_a_pure_function_of_the_timings():
+    """mispmm_autotune_pick: candidate 0 (storage order) is kept unless another is at least min_gain faster; a candidate that
+    could not run (inf), a zero or a NaN never wins; ties and noise inside the margin keep the default -- the same timings give
+    the same choice, whatever produced them."""
+    pick = ops.autotune_pick
+    assert pick([12.6, 11.1]) == 1 and pick([3.47, 3.69]) == 0 and pick([13.60, 12.99]) == 1
+    assert pick([10.0, 9.85]) == 0 and pick([10.0, 9.79]) == 1                 # 2 % margin
+    assert pick([10.0, float("inf")]) == 0 and pick([float("inf"), 5.0]) == 1 and pick([10.0, float("nan")]) == 0
+    assert pick([10.0, 0.0]) == 0 and pick([10.0, 9.0, 8.0]) == 2 and pick([10.0, 9.9, 9.85]) == 0
+    assert pick([10.0, 9.0], min_gain=0.2) == 0
+    assert all(pick([12.6, 11.1]) == 1 for _ in range(5))
+
+
+def test_autotune_takes_the_plan_the_footprint_rule_misses():
+    """ACTIVSg10K x K=256: 2.6 MB of B per XCD fit the L2, so the footprint rule says "storage order" -- measured, the clustered
+    plan order is faster (12.6 -> 11.1 us, DESIGN.md section 9.4 of round 3).  The autotune measures it and takes the plan; the
+    headline (n4c6-b13 x K=128: plan +6 %) keeps the storage order.  Timings are printed into the assertion message."""
+    csr = datasets.load_csr("ACTIVSg10K")
+    a = ops.DeviceCSR.from_host(csr, spans=False)
+    assert a.plan is not None and not ops.plan_pays(csr.num_cols, 256)
+    ops.spmm_csr(a, dev(synth.dense_b(csr.num_cols, 256)))
+    use, times = a.tuned[(256, "reference")]
+    assert use == (ops.autotune_pick(times) == 1), times
+    head = ops.DeviceCSR.from_host(datasets.load_csr("n4c6-b13"))
+    ops.spmm_csr(head, dev(synth.dense_b(head.num_cols, 128)))
+    h_use, h_times = head.tuned[(128, "reference")]
+    assert h_use == (ops.autotune_pick(h_times) == 1), h_times
+    print("autotune ACTIVSg10K x 256:", use, times, "| n4c6-b13 x 128:", h_use, h_times)
 
 
 @pytest.mark.parametrize("n", [128, 40, 6])

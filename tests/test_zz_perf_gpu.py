@@ -25,7 +25,7 @@ CLI = os.path.join(ROOT, "cuda-optimization-for-spmm_amd", "cuspmm")
 
 # resident loop (`roofline.frac`) and HBM-streamed loop (`hbm_streaming.frac`) per BASELINE configuration: kept figure, floor
 RESIDENT = {"headline": (0.605, 0.55), "2": (0.21, 0.19), "3": (0.72, 0.66), "4": (0.537, 0.49), "5": (0.63, 0.575)}
-STREAMED = {"headline": 0.40, "2": 0.12, "3": 0.45, "4": 0.35, "5": 0.42}
+STREAMED = {"headline": (0.338, 0.31), "2": (0.16, 0.14), "3": (0.337, 0.30), "4": (0.46, 0.42), "5": (0.416, 0.38)}
 
 
 def _records(stdout):
@@ -37,7 +37,7 @@ def test_bench_line_perf_floors(bench_line, cfg):
     line = bench_line(cfg)
     kept, floor = RESIDENT[cfg]
     assert line["roofline"]["frac"] >= floor, (cfg, kept, line["roofline"])
-    assert line["hbm_streaming"]["frac"] >= STREAMED[cfg], (cfg, line["hbm_streaming"])
+    assert line["hbm_streaming"]["frac"] >= STREAMED[cfg][1], (cfg, STREAMED[cfg][0], line["hbm_streaming"])
     # streaming B and C from / to HBM cannot be faster than finding them in the Infinity Cache (5 % for the noise of two loops)
     assert line["hbm_streaming"]["launch_us"] >= 0.95 * line["roofline"]["launch_us"], (cfg, line["hbm_streaming"], line["roofline"])
 
