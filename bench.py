@@ -520,7 +520,11 @@ def live_traffic(args, operand_sets=1):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             proc = subprocess.Popen(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, stdout=subprocess.PIPE,
-                                    stderr=subprocess.PIPE, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", start_new_session=True)
+                                    stderr=subprocess.PIPE, text=True, cwd="/tmp", start_new_session=True,
+                                    # MISPMM_AUTOTUNE=0: under the profiler (serialised, slower launches) the plan-vs-storage-order measurement
+                                    # can come out differently from the parent's; the footprint rule gives the parent's choice on every
+                                    # BASELINE configuration, and the kernel tags are compared anyway before the figure is used
+                                    env=dict(os.environ, TMPDIR="/tmp", MISPMM_AUTOTUNE="0"))
             try:
                 stdout, stderr = proc.communicate(timeout=150)
             except subprocess.TimeoutExpired:

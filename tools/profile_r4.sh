@@ -12,6 +12,9 @@ MODE=$1
 OUT=$2
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the footprint rule instead of the plan-order autotune: under the profiler (serialised launches) the two candidates time
+# differently and the profiled run could take another kernel than the bench line it is evidence for
+export MISPMM_AUTOTUNE=0
 COMMON="--steps 20 --warmup 5 --no-cpu-baseline --no-extras --placements 1 --no-live-traffic"
 
 digest() {  # <trace dir> <digest file> <header>
