@@ -919,7 +919,10 @@ def run_multi(args):
         unit = bucket // int(np.gcd(args.steps, bucket))       # replays that make K * R a whole number of buckets
         replays = -(-replays // unit) * unit
         wall = timed(args.steps * replays, True) / replays
-        # the same steps with C left row-sharded (no exchange): the kernel-only figure
+        # the same steps with C left row-sharded (no exchange): the kernel-only figure.  One untimed bucket first: the graph of
+        # the kernel-only steps is captured and instantiated on first use (a 500-launch graph: milliseconds of host time)
+        job.run(job.bucket, gather=False)
+        job.finish(gather=False)
         compute_s = timed(args.steps * replays, False) / replays
         # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
         job.run(1)

@@ -857,25 +857,22 @@ extern "C" int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, 
     float times[2] = {inf, inf};
     if (times_us_out) times_us_out[0] = times_us_out[1] = inf;
     if (M == 0 || N == 0 || nnz == 0 || !planRowMap || !planColIdxs || !planVals) return MISPMM_OK;   // nothing to choose from
-    if (launches == 0) launches = 64;
+    if (launches == 0) launches = 48;
+    // Timed with plain launches on the CALLER's stream.  (A version that replayed each candidate from a graph on a stream of its
+    // own discriminated kernels of a few microseconds better -- launched one by one those run at the host's launch rate -- but
+    // left the process slower: every later launch of the K = 512 product took 13.55 instead of 12.98 us, same kernel, same
+    // operands, profiles/r4/autotune_side_effect.log.  The plan order only ever wins on products of 10 us and more, where
+    // plain launches time true; on shorter ones both candidates read the launch rate, tie, and the default is kept.)
+    hipStream_t st = as_stream(stream);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (stream && hipStreamIsCapturing(as_stream(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
         return fail(MISPMM_ERR_INVALID_ARG, "autotune: the stream is being captured");
-    // measured on a stream of its own (the caller's may be the legacy default stream, which cannot be captured), behind
-    // whatever the caller's stream still has in flight
-    MISPMM_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
-    hipStream_t st = nullptr;
-    MISPMM_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    stream = reinterpret_cast<mispmm_stream_t>(st);
     float *B = nullptr, *C = nullptr;
     const size_t b_elems = static_cast<size_t>(K) * N, c_elems = static_cast<size_t>(M) * N;
-    if (hipMalloc(&B, b_elems * sizeof(float)) != hipSuccess) {
-        (void)hipStreamDestroy(st);
+    if (hipMalloc(&B, b_elems * sizeof(float)) != hipSuccess)
         return fail(MISPMM_ERR_ALLOC, "autotune: no memory for the scratch B (%zu bytes)", b_elems * sizeof(float));
-    }
     if (hipMalloc(&C, c_elems * sizeof(float)) != hipSuccess) {
         (void)hipFree(B);
-        (void)hipStreamDestroy(st);
         return fail(MISPMM_ERR_ALLOC, "autotune: no memory for the scratch C (%zu bytes)", c_elems * sizeof(float));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -883,7 +880,6 @@ extern "C" int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, 
     auto cleanup = [&] {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
-        (void)hipStreamDestroy(st);
         (void)hipFree(B);
         (void)hipFree(C);
     };
@@ -906,31 +902,15 @@ extern "C" int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, 
         for (int i = 0; i < 3 && rs == MISPMM_OK; ++i) rs = run(which);               // warm: code, caches, clocks
         if (rs == MISPMM_ERR_UNSUPPORTED) continue;                                   // this candidate does not take the shape
         if (rs != MISPMM_OK) { status = rs; break; }
-        // the launches replayed from ONE graph: launched one by one from the host, kernels of a few microseconds run at the
-        // host's launch rate (~3.5 us each) and two candidates of 3.4 and 3.7 us read the same
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        if (hipStreamSynchronize(st) != hipSuccess || hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { status = MISPMM_ERR_HIP; break; }
-        for (uint32_t i = 0; i < launches && rs == MISPMM_OK; ++i) rs = run(which);
-        const hipError_t ce = hipStreamEndCapture(st, &graph);
-        if (rs != MISPMM_OK || ce != hipSuccess || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            if (graph) (void)hipGraphDestroy(graph);
-            status = rs != MISPMM_OK ? rs : MISPMM_ERR_HIP;
-            break;
-        }
         float best = inf;
-        (void)hipGraphLaunch(exec, st);                                               // upload
         for (int round = 0; round < 3; ++round) {
             (void)hipEventRecord(e0, st);
-            (void)hipGraphLaunch(exec, st);
-            (void)hipGraphLaunch(exec, st);
+            for (uint32_t i = 0; i < launches && rs == MISPMM_OK; ++i) rs = run(which);
             (void)hipEventRecord(e1, st);
-            if (hipEventSynchronize(e1) != hipSuccess) { status = MISPMM_ERR_HIP; break; }
+            if (rs != MISPMM_OK || hipEventSynchronize(e1) != hipSuccess) { status = rs != MISPMM_OK ? rs : MISPMM_ERR_HIP; break; }
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) best = std::min(best, ms * 1e3f / static_cast<float>(2u * launches));
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) best = std::min(best, ms * 1e3f / static_cast<float>(launches));
         }
-        (void)hipGraphExecDestroy(exec);
-        (void)hipGraphDestroy(graph);
         times[which] = best;
     }
     (void)hipStreamSynchronize(st);

@@ -216,9 +216,9 @@ int mispmm_csr_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t
 /* Autotune (round 4): whether a product of THIS matrix with a dense operand of N columns is faster from the plan-order arrays
  * or from the storage-order ones is MEASURED, once per (matrix, N), instead of guessed from a footprint rule (the rule the
  * measurements of round 3 gave -- plan where the B slice of an XCD exceeds its L2 -- misses e.g. ACTIVSg10K x N = 256:
- * 12.6 -> 11.1 us with the plan).  Scratch B (ones) and C are allocated, each candidate is warmed, captured as ONE graph of
- * `launches` launches (0 = 64; replayed from a graph because launches of a few microseconds issued one by one run at the host's
- * launch rate) and timed over 3 rounds of two replays between HIP events on `stream`, the scratch is freed; times_us_out[0] = storage
+ * 12.6 -> 11.1 us with the plan).  Scratch B (ones) and C are allocated, each candidate is warmed and then timed over 3 rounds
+ * of `launches` plain launches (0 = 48) between HIP events on `stream` (kernels of a few microseconds run at the host's launch
+ * rate this way and tie, which keeps the default: the plan only wins on products of 10 us and more), the scratch is freed; times_us_out[0] = storage
  * order (mispmm_csr_uniform_f32 / mispmm_csr_f32 kernel auto), [1] = plan order, a candidate the shape does not support = +inf.
  * *use_plan_out = mispmm_autotune_pick(times, 2, 0.02) == 1.  Synchronises `stream`; never call it while the stream is being
  * captured.  The format objects (SparseMatrixCSR::copy2Device's caller, DeviceCSR) call it on the first product of a width and

@@ -72,7 +72,7 @@ for c in headline 2 3 4 5; do
   [ $c = headline ] || pmc_pass "pmc_cfg${c}_1" "--config $c $COMMON" FETCH_SIZE
   [ $c = headline ] || pmc_pass "pmc_cfg${c}_2" "--config $c $COMMON" WRITE_SIZE TCC_REQ_sum
   pmc_pass "pmc_stream${c}_1" "--config $c $COMMON --operand-sets 0" FETCH_SIZE
-  pmc_pass "pmc_stream${c}_2" "--config $c $COMMON --operand-sets 0" WRITE_SIZE TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
+  pmc_pass "pmc_stream${c}_2" "--config $c $COMMON --operand-sets 0" WRITE_SIZE TCC_REQ_sum
 done
 export MISPMM_NO_HINT=1
 pmc_pass "pmc_nohint_1" "--config headline $COMMON" FETCH_SIZE
