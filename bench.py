@@ -34,7 +34,8 @@ un-warmed launch per kernel (reference/src/engine/engine.cpp:41-44) -- without t
 child under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE: separate passes, eager launches); profiles/r3/traffic.json is the
 fallback (--no-extras / --no-live-traffic skip the passes).
 
-N > 1.  Started plainly (`python bench.py --gpus N`), this process spawns its N ranks itself (children, before
+N > 1 (--config headline | 3 | 4 | 5: CSR by rows, ELL by rows, bf16 BSR-16 by block rows).  Started plainly
+(`python bench.py --gpus N`), this process spawns its N ranks itself (children, before
 it makes any GPU call); under torch.distributed.run it is one of the ranks.  Rows of A are cut into N contiguous
 nnz-balanced ranges, B is broadcast once (outside the timed region), every rank multiplies its slab each step
 and the C row slabs are exchanged in buckets: `allgather` (RCCL all_gather_into_tensor on a second stream) or
@@ -778,28 +779,74 @@ def run_multi(args):
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     capi.lib()
-    if args.config not in ("headline", "5"):
-        # the sharded path is BASELINE.json's: CSR rows over the GPUs (headline at N = 1, 2, 4, 8; configs[4] = K 512).  Refuse
-        # rather than print a CSR line under another configuration's name.
-        raise SystemExit(f"bench: --gpus N shards the CSR configurations (--config headline | 5); --config {args.config} is a single-GPU configuration")
-    cfg_matrix = args.matrix or "n4c6-b13"
-    n = args.k_cols or (512 if args.config == "5" else 128)
+    if args.config == "2":
+        # medium_4096 is a 4 MB problem whose step is the launch boundary: sharding it measures nothing
+        raise SystemExit("bench: --gpus N shards --config headline | 3 | 4 | 5; --config 2 is a single-GPU configuration")
+    from mispmm import formats, ops
+    fmt = {"3": "ell", "4": "bsr"}.get(args.config, "csr")
+    cfg_matrix = args.matrix or ("ACTIVSg10K" if fmt == "bsr" else "n4c6-b13")
+    n = args.k_cols or {"headline": 128, "3": 256, "4": 128, "5": 512}[args.config]
     csr = datasets.load_csr(cfg_matrix)
     bucket = args.bucket if args.bucket > 0 else 64
     modes = ["allgather", "peer"] if args.exchange == "both" else [args.exchange]
     b_host = synth.dense_b(csr.num_cols, n) if rank == 0 else None
     flops = datasets.spmm_flops(csr.nnz, n)
-    abytes = datasets.csr_algorithmic_bytes(csr, n)
     results, whole, gathered_host = {}, None, None
-    shard_bounds = mdist.shard_bounds(csr.row_ptrs, world)
+    # what is sharded, how a rank's driver is built, what the unsharded single-GPU product is (the checker of the exchange),
+    # and the algorithmic bytes of a shard -- per format: CSR by rows, ELL by rows, bf16 BSR-16 by block rows
+    if fmt == "csr":
+        operand, abytes = csr, datasets.csr_algorithmic_bytes(csr, n)
+        shard_bounds = mdist.shard_bounds(csr.row_ptrs, world)
+        kind, esize = "CSR", 4
+
+        def make_job(mode, **kw):
+            return mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode, **kw)
+
+        def unsharded(b_dev):
+            return ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=device), b_dev, kernel=args.kernel, acc=args.acc)
+
+        def shard_a_bytes(r0, r1, e0, e1):
+            return (e1 - e0) * 8 + (r1 - r0 + 1) * 4
+    elif fmt == "ell":
+        operand = ops.colmajor_ell_to_rowmajor(formats.csr_to_ell_colmajor(csr))
+        abytes = datasets.ell_algorithmic_bytes(csr.num_rows, operand.width, csr.num_cols, n)
+        shard_bounds = mdist.ShardedEllSpmm._partition(None, operand, world)
+        kind, esize = "ELL", 4
+
+        def make_job(mode, **kw):
+            return mdist.ShardedEllSpmm(operand, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode, **kw)
+
+        def unsharded(b_dev):
+            return ops.spmm_ell(ops.DeviceELL.from_host(operand, device=device), b_dev, kernel=args.kernel, acc=args.acc)
+
+        def shard_a_bytes(r0, r1, e0, e1):
+            return (r1 - r0) * operand.width * 8
+    else:
+        operand = formats.csr_to_bsr(csr, 16)
+        shard_bounds = mdist.ShardedBsrcSlotsSpmm._partition(None, operand, world)
+        kind, esize = "BSR block 16", 2
+        abytes = None                                             # the bytes of the kernel's operand: summed over the shards below
+
+        def make_job(mode, **kw):
+            return mdist.ShardedBsrcSlotsSpmm(operand, n, device=device, bucket=bucket, exchange=mode, **kw)
+
+        def unsharded(b_dev):
+            return ops.spmm_bsrc_slots_bf16(ops.DeviceBSRCSlots.from_host(operand, device=device), b_dev, out_bf16=False)
+
+        def shard_a_bytes(r0, r1, e0, e1):
+            from mispmm.multi import bsr_block_row_slice
+            local = ops.DeviceBSRCSlots.from_host(bsr_block_row_slice(operand, r0 // 16, r1 // 16), device=device)
+            return local.operand_bytes()
     # who took part: every rank reports its device (PCI bus id) and the algorithmic bytes of ITS shard -- its slice of A,
     # the B rows its columns touch, its C slab ("multi-GPU per device ... node total = sum")
     r0, r1 = int(shard_bounds[rank]), int(shard_bounds[rank + 1])
-    e0, e1 = int(csr.row_ptrs[r0]), int(csr.row_ptrs[r1])
+    e0, e1 = int(csr.row_ptrs[min(r0, csr.num_rows)]), int(csr.row_ptrs[min(r1, csr.num_rows)])
     touched = int(np.unique(csr.col_idxs[e0:e1]).size)
     mine = {"rank": rank, "device": dev_index, "bus_id": capi.device_bus_id(dev_index), "host": os.uname().nodename,
             "rows": r1 - r0, "nnz": e1 - e0, "b_rows_touched": touched,
-            "algorithmic_bytes": (e1 - e0) * 8 + (r1 - r0 + 1) * 4 + touched * n * 4 + (r1 - r0) * n * 4}
+            "algorithmic_bytes": int(shard_a_bytes(r0, r1, e0, e1) + touched * n * esize + (r1 - r0) * n * 4)}
+    if abytes is None:                                            # config 4 on one GPU: the unsharded operand of the same kernel
+        abytes = int(ops.DeviceBSRCSlots.from_host(operand, device=device).operand_bytes() + csr.num_cols * n * 2 + csr.num_rows * n * 4)
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     extras = {}                      # legs measured beside the exchange modes (kernel_only_batched)
@@ -812,21 +859,22 @@ def run_multi(args):
             raise SystemExit(f"bench: no exchange mode could run: {results}")
         best = max(usable, key=lambda m: usable[m]["value"])
         r = usable[best]
-        label = "large_25605" if cfg_matrix == "n4c6-b13" else cfg_matrix
+        label = {"n4c6-b13": "large_25605", "ACTIVSg10K": "large_20000"}.get(cfg_matrix, cfg_matrix)
         node_bytes = int(sum(e["algorithmic_bytes"] for e in everyone))
         devices_seen = sorted({(e["host"], e["bus_id"]) for e in everyone})
         ko_s, e2e_s = r["kernel_only_ms_per_step"] * 1e-3, r["ms_per_step"] * 1e-3
         out = {
-            "metric": f"SpMM GFLOP/s, {label} ({cfg_matrix}) CSR x dense K={n} fp32",
+            "metric": f"SpMM GFLOP/s, {label} ({cfg_matrix}) {kind} x dense K={n} {'bf16' if fmt == 'bsr' else 'fp32'}",
             "value": r["value"], "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if fmt == "bsr" else "f32",
             "data": f"SuiteSparse {cfg_matrix} (reference data/{label}) x seeded synthetic B",
-            "config": {"workload": f"{cfg_matrix} CSR {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} fp32",
-                       "parallelism": f"row-sharded x{world}, B replicated, C slabs exchanged every {bucket} steps "
+            "config": {"workload": f"{cfg_matrix} {kind} {csr.num_rows}x{csr.num_cols} nnz {csr.nnz} x dense K={n} {'bf16, C fp32' if fmt == 'bsr' else 'fp32'}",
+                       "parallelism": f"{'block-row' if fmt == 'bsr' else 'row'}-sharded x{world}, B replicated, C slabs exchanged every {bucket} steps "
                                       f"({best}: " + ("RCCL all_gather_into_tensor" if best == "allgather" else
                                                       "direct copies into IPC-mapped peer buffers over xGMI") + ")",
-                       "kernel": args.kernel, "kernel_tag": shard_kernel_tag.get("tag"), "acc_mode": args.acc,
+                       "kernel": args.kernel, "kernel_tag": shard_kernel_tag.get("tag"),
+                       "acc_mode": args.acc if fmt != "bsr" else "fp32 accumulate (MFMA)", "format": fmt,
                        "check": "exchanged C == unsharded single-GPU C (bitwise) on every rank"},
             "ranks_seen": {"world_size": world, "distinct_devices": len(devices_seen),
                            "devices": [f"{h}/{b}" for h, b in devices_seen],
@@ -853,7 +901,16 @@ def run_multi(args):
         if not args.no_cpu_baseline:
             # the same CPU leg as at N = 1: the oracle, 1 thread, rank 0's host, and the checker of the exchanged C
             if "cpu" not in cache:
-                shim = CsrWorkload.__new__(CsrWorkload)
+                if fmt == "csr":
+                    shim = CsrWorkload.__new__(CsrWorkload)
+                elif fmt == "ell":
+                    shim = EllWorkload.__new__(EllWorkload)
+                    shim.ellc = formats.csr_to_ell_colmajor(csr)
+                else:
+                    shim = BsrBf16Workload.__new__(BsrBf16Workload)
+                    shim.bsr, shim.block = operand, 16
+                    shim.a16_host = synth.bf16_round(operand.data.reshape(-1)).reshape(operand.data.shape)
+                    shim.b16_host = synth.bf16_round(b_host.reshape(-1)).reshape(b_host.shape)
                 shim.csr, shim.b_host, shim.flops, shim.n = csr, b_host, flops, n
                 shim.workload = out["config"]["workload"]
                 cache["cpu"] = cpu_baseline(shim, args.cpu_seconds, gathered_host, args.acc)
@@ -882,8 +939,7 @@ def run_multi(args):
         if stall == mode + ":die":
             os._exit(9)
         try:
-            job = mdist.ShardedCsrSpmm(csr, n, device=device, kernel=args.kernel, acc=args.acc, bucket=bucket, exchange=mode,
-                                       debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
+            job = make_job(mode, debug_sentinel=os.environ.get("MISPMM_DIST_DEBUG") == "1")
         except Exception as e:  # noqa: BLE001  (the peer path needs IPC mapping between the ranks' devices)
             results[mode] = {"unavailable": f"{type(e).__name__}: {e}"}
             job = None
@@ -927,9 +983,8 @@ def run_multi(args):
         # exchanged C must equal the unsharded single-GPU product bit for bit (row independence), on every rank
         job.run(1)
         job.finish()
-        from mispmm import ops
         if whole is None:
-            whole = ops.spmm_csr(ops.DeviceCSR.from_host(csr, device=device), job.b, kernel=args.kernel, acc=args.acc)
+            whole = unsharded(job.b)
             torch.cuda.synchronize()
         ok = torch.tensor([1.0 if torch.equal(whole, job.gathered_c()) else 0.0], device="cpu" if shared_gpu else device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -1020,7 +1075,7 @@ def run_multi(args):
                 watchdog.cancel()
         persist()
         dist.barrier()       # no rank enters the next mode (where a fault may take the job down) before rank 0 has persisted this one
-    if args.batch > 1 and any("value" in r for r in results.values()):
+    if args.batch > 1 and fmt == "csr" and any("value" in r for r in results.values()):
         try:
             run_batched()
         except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)

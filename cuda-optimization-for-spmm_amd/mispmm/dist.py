@@ -69,6 +69,20 @@ def csr_row_slice(csr, r0, r1):
 
 
 class ShardedCsrSpmm:
+    """CSR sharded by rows.  ShardedEllSpmm (ELL by rows) and ShardedBsrcSlotsSpmm (bf16 BSR-16 by block rows) below reuse
+    everything but the four hooks `_partition`, `_make_local`, `_alloc_b` and `_hip_compute`."""
+    b_dtype = torch.float32
+
+    # -- hooks -------------------------------------------------------------------------------------
+    def _partition(self, csr, world):
+        """Row bounds of the shards, nnz-balanced (int64 array of world + 1 C-row indices)."""
+        return shard_bounds(csr.row_ptrs, world)
+
+    def _make_local(self, csr, r0, r1):
+        local = csr_row_slice(csr, r0, r1)
+        self.local_nnz = local.nnz
+        return ops.DeviceCSR.from_host(local, device=self.device)
+
     def __init__(self, csr, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather",
                  debug_sentinel=False, batch=1):
         if exchange not in ("allgather", "peer"):
@@ -85,14 +99,12 @@ class ShardedCsrSpmm:
             raise ValueError("at most 16 dense operands per launch (mispmm_csr_batch_f32)")
         self.bucket = -(-self.bucket // self.batch) * self.batch     # whole launches per bucket
         self.num_rows, self.num_cols = csr.num_rows, csr.num_cols
-        self.bounds = shard_bounds(csr.row_ptrs, self.world)
+        self.bounds = np.asarray(self._partition(csr, self.world), dtype=np.int64)
         self.r0, self.r1 = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
         self.rows = self.r1 - self.r0
         self.slab_rows = max(1, int(np.diff(self.bounds).max()))
-        local = csr_row_slice(csr, self.r0, self.r1)
-        self.local_nnz = local.nnz
-        self.a = ops.DeviceCSR.from_host(local, device=self.device)
-        self.b = torch.zeros((self.num_cols, self.n), dtype=torch.float32, device=self.device)
+        self.a = self._make_local(csr, self.r0, self.r1)
+        self.b = torch.zeros((self.num_cols, self.n), dtype=self.b_dtype, device=self.device)
         # two bucket-sized slab rings and gather targets: one being filled, one being gathered
         self.ring = [torch.zeros((self.bucket, self.slab_rows, self.n), dtype=torch.float32, device=self.device)
                      for _ in range(2)]
@@ -189,15 +201,20 @@ class ShardedCsrSpmm:
         ops.spmm_csr(a, b, out=out, kernel=self.kernel, acc=self.acc, stream=self.compute_stream)
 
     # -- one-time B replication ------------------------------------------------------------------
+    def _load_b(self, b_host):
+        """rank 0: the fp32 host operand into this rank's device copy (the bf16 shards round it on the device)"""
+        self.b.copy_(torch.from_numpy(np.ascontiguousarray(b_host, dtype=np.float32)))
+
     def broadcast_b(self, b_host):
         if self.rank == 0:
-            self.b.copy_(torch.from_numpy(np.ascontiguousarray(b_host, dtype=np.float32)))
+            self._load_b(b_host)
+        wire = self.b.view(torch.uint8) if self.b.dtype == torch.int16 else self.b    # bf16 bit patterns travel as bytes (RCCL has no int16)
         if self.on_gpu and dist.get_backend() != "nccl":
-            staged = self.b.cpu()                 # a CPU-only backend (gloo rehearsal on one card): broadcast on the host
+            staged = wire.cpu()                   # a CPU-only backend (gloo rehearsal on one card): broadcast on the host
             dist.broadcast(staged, src=0)
-            self.b.copy_(staged)
+            wire.copy_(staged)
         else:
-            dist.broadcast(self.b, src=0)
+            dist.broadcast(wire, src=0)
         self.b_replicas = [self.b] + [self.b.clone() for _ in range(self.batch - 1)]
         if self.on_gpu:
             torch.cuda.synchronize(self.device)
@@ -349,3 +366,61 @@ class ShardedCsrSpmm:
             return self.local_c[operand, :self.rows]
         buf, s = self.last_local
         return self.ring[buf][s, :self.rows]
+
+
+class ShardedEllSpmm(ShardedCsrSpmm):
+    """ELL sharded by rows: `ell` is a formats.ELLRowMajor (or the reference's column-major ELL,
+    converted once); rows are cut into contiguous ranges balanced by occupied slots; every rank multiplies its rows with
+    mispmm_ell_f32 -- the reference's ELL arithmetic (fp32 product, fp32 add in slot order), so the gathered C equals the
+    unsharded ELL product bit for bit."""
+
+    def __init__(self, ell, n_cols, device, kernel=0, acc="reference", bucket=16, compute=None, exchange="allgather", debug_sentinel=False):
+        if isinstance(ell, formats.ELLColMajor):
+            ell = ops.colmajor_ell_to_rowmajor(ell)
+        super().__init__(ell, n_cols, device, kernel=kernel, acc=acc, bucket=bucket, compute=compute, exchange=exchange,
+                         debug_sentinel=debug_sentinel, batch=1)
+
+    def _partition(self, ell, world):
+        cols = np.asarray(ell.col_idxs, dtype=np.uint32).reshape(ell.num_rows, -1)
+        occupied = np.concatenate([[0], np.cumsum((cols != 0xFFFFFFFF).sum(axis=1))]).astype(np.uint32)
+        return shard_bounds(occupied, world)
+
+    def _make_local(self, ell, r0, r1):
+        cols = np.asarray(ell.col_idxs, dtype=np.uint32).reshape(ell.num_rows, -1)[r0:r1]
+        vals = np.asarray(ell.data, dtype=np.float32).reshape(ell.num_rows, -1)[r0:r1]
+        self.local_nnz = int((cols != 0xFFFFFFFF).sum())
+        local = formats.ELLRowMajor(r1 - r0, ell.num_cols, self.local_nnz, ell.width, cols, vals)
+        return ops.DeviceELL.from_host(local, device=self.device, compact=False) if self.device.type == "cuda" else local
+
+    def _hip_compute(self, a, b, out):
+        ops.spmm_ell(a, b, out=out, kernel=self.kernel, acc=self.acc, stream=self.compute_stream)
+
+
+class ShardedBsrcSlotsSpmm(ShardedCsrSpmm):
+    """bf16 BSR-16 sharded by BLOCK rows (BASELINE config 4's kernel on every shard): block rows are
+    cut into ranges balanced by block count, every shard is compacted into fixed step slots on its own (the same columns per
+    block row as the unsharded compaction, so the gathered C equals the unsharded kernel's C bit for bit).  B is rounded to
+    bf16 once on rank 0 and broadcast as bf16; C is fp32."""
+    b_dtype = torch.int16
+
+    def __init__(self, bsr, n_cols, device, bucket=16, compute=None, exchange="allgather", debug_sentinel=False):
+        if bsr.block_row_size != 16 or bsr.block_col_size != 16:
+            raise ValueError("16 x 16 blocks (BASELINE config 4)")
+        super().__init__(bsr, n_cols, device, kernel=0, acc="reference", bucket=bucket, compute=compute, exchange=exchange,
+                         debug_sentinel=debug_sentinel, batch=1)
+
+    def _partition(self, bsr, world):
+        return shard_bounds(bsr.block_row_ptrs, world) * 16              # C rows
+
+    def _make_local(self, bsr, r0, r1):
+        from .multi import bsr_block_row_slice
+        local = bsr_block_row_slice(bsr, r0 // 16, r1 // 16)
+        self.local_nnz = int(local.num_blocks) * 256
+        return ops.DeviceBSRCSlots.from_host(local, device=self.device) if self.device.type == "cuda" else local
+
+    def _load_b(self, b_host):
+        self.b.copy_(ops.f32_to_bf16(torch.from_numpy(np.ascontiguousarray(b_host, dtype=np.float32)).to(self.device)))
+
+    def _hip_compute(self, a, b, out):
+        ops.spmm_bsrc_slots_bf16(a, b, out_bf16=False, out=out, stream=self.compute_stream)
+

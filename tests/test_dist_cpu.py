@@ -73,6 +73,51 @@ def test_sharded_spmm_gloo(tmp_path, world, matrix, n, bucket, steps):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
+def _ell_worker(rank, world, port, matrix, n, bucket, steps, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "cuda-optimization-for-spmm_amd")]
+    from mispmm import datasets, formats, synth
+    from mispmm import dist as mdist
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        csr = datasets.load_csr(matrix)
+        ellc = formats.csr_to_ell_colmajor(csr)
+        rows = np.repeat(np.arange(csr.num_rows, dtype=np.uint32), np.diff(csr.row_ptrs.astype(np.int64)))
+
+        def compute(a, b, out):     # the oracle's ELL arithmetic (fp32 product, fp32 add in slot order) on the rank's rows
+            cols = np.asarray(a.col_idxs, dtype=np.uint32).reshape(a.num_rows, -1)
+            vals = np.asarray(a.data, dtype=np.float32).reshape(a.num_rows, -1)
+            live = cols != 0xFFFFFFFF
+            r = np.repeat(np.arange(a.num_rows, dtype=np.uint32), live.sum(axis=1))
+            out.copy_(torch.from_numpy(orc.spmm_coo(a.num_rows, r, cols[live], vals[live], b.numpy())))
+
+        job = mdist.ShardedEllSpmm(ellc, n, device="cpu", bucket=bucket, compute=compute)
+        job.broadcast_b(synth.dense_b(csr.num_cols, n) if rank == 0 else None)
+        job.run(steps)
+        job.finish()
+        full_b = synth.dense_b(csr.num_cols, n)
+        ref = orc.spmm_ell_colmajor(ellc.num_rows, ellc.row_idxs, ellc.data, full_b)
+        assert np.array_equal(job.gathered_c().numpy(), ref), "gathered C differs from the unsharded ELL product"
+        assert np.array_equal(ref, orc.spmm_coo(csr.num_rows, rows, csr.col_idxs, csr.data, full_b))
+        b = job.bounds
+        assert b[0] == 0 and b[-1] == csr.num_rows and np.all(np.diff(b) >= 0) and job.local_nnz > 0
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,matrix,n,bucket,steps", [(2, "qh1484", 16, 3, 4), (3, "n3c5-b6", 8, 2, 3)])
+def test_sharded_ell_gloo(tmp_path, world, matrix, n, bucket, steps):
+    """ShardedEllSpmm (ELL by rows) over gloo with the oracle as the per-rank compute step: partition
+    by occupied slots, padded slab ring, bucketed all-gather, reassembly -- the gathered C equals the unsharded ELL product."""
+    port = _free_port()
+    mp.spawn(_ell_worker, args=(world, port, matrix, n, bucket, steps, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
 def test_row_slice_is_a_standalone_csr():
     from mispmm import datasets
     from mispmm import dist as mdist

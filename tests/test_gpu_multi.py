@@ -245,12 +245,56 @@ def test_sharded_driver_kernel_only_steps_resident_and_batched(oracle, nccl_worl
         job.close()
 
 
-def _bench(*args, env=None, expect_rc=0):
+def test_sharded_ell_and_bf16_bsr_drivers_over_rccl_world_size_one(oracle, nccl_world_of_one):
+    """ShardedEllSpmm / ShardedBsrcSlotsSpmm (one process per GPU; here one rank over RCCL): bucket graphs, the exchange on
+    its own stream, a partial bucket -- the gathered C equals the unsharded single-GPU product bit for bit (ELL: and the
+    oracle's; bf16 BSR: the oracle within the bf16 bound)."""
+    from mispmm import dist as mdist, formats
+    csr = datasets.load_csr("n4c6-b13")
+    ellc = formats.csr_to_ell_colmajor(csr)
+    b = synth.dense_b(csr.num_cols, 256)
+    ref = oracle.spmm_ell_colmajor(ellc.num_rows, ellc.row_idxs, ellc.data, b)
+    job = mdist.ShardedEllSpmm(ellc, 256, device=torch.device("cuda", 0), bucket=4)
+    job.broadcast_b(b)
+    job.run(4 * 2 + 3)
+    job.finish()
+    assert np.array_equal(job.gathered_c().cpu().numpy(), ref)
+    job.run(5, gather=False)
+    job.finish(gather=False)
+    assert np.array_equal(job.local_slab().cpu().numpy(), ref)
+    job.close()
+    big = datasets.load_csr("ACTIVSg10K")
+    bsr = formats.csr_to_bsr(big, 16)
+    bb = synth.dense_b(big.num_cols, 128)
+    whole = ops.spmm_bsrc_slots_bf16(ops.DeviceBSRCSlots.from_host(bsr), ops.f32_to_bf16(dev(bb)))
+    for exchange in ("allgather", "peer"):
+        job = mdist.ShardedBsrcSlotsSpmm(bsr, 128, device=torch.device("cuda", 0), bucket=4, exchange=exchange)
+        job.broadcast_b(bb)
+        job.run(4 + 2)
+        job.finish()
+        assert torch.equal(job.gathered_c(), whole), exchange
+        job.close()
+
+
+def test_bench_shards_the_ell_and_bsr_configurations():
+    """`bench.py --gpus 2 --config 3 | 4` (two ranks sharing the card): the ELL and the bf16 BSR configuration go through the
+    same driver as the CSR ones -- exchanged C == unsharded single-GPU C on every rank, the CPU leg checks it against the
+    oracle (ELL bit-exact, bf16 BSR within its bound), the line names the format."""
+    for cfg, fmt, parity in (("3", "ell", "bit-exact"), ("4", "bsr", "within 2e-6")):
+        line = _bench("--gpus", "2", "--config", cfg, "--steps", "8", "--warmup", "2", "--bucket", "4", "--cpu-seconds", "1",
+                      env={"MISPMM_SHARE_GPU": "1"})
+        assert line["n_gpus"] == 2 and line["config"]["format"] == fmt and parity in line["cpu_baseline"]["gpu_parity"]
+        assert "value" in line["exchange_modes"]["allgather"] and "kernel_only_batched" not in line
+        assert len(line["ranks_seen"]["per_rank"]) == 2 and sum(r["rows"] for r in line["ranks_seen"]["per_rank"]) in (6300, 20000)
+    line = _bench("--gpus", "2", "--config", "2", env={"MISPMM_SHARE_GPU": "1"}, expect_rc=1, parse=False)
+
+
+def _bench(*args, env=None, expect_rc=0, parse=True):
     e = {k: v for k, v in os.environ.items() if k not in ("MASTER_PORT", "MASTER_ADDR", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == expect_rc, (p.returncode, p.stderr[-3000:])
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    return json.loads(p.stdout.strip().splitlines()[-1]) if parse else p
 
 
 def test_bench_distributed_path_single_rank_over_rccl():
