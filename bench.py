@@ -658,9 +658,12 @@ def run_single(args):
                      "note": "launch_us = HIP-event time of the timed region / launches in it (inter-kernel gaps "
                              "included); traffic = L2<->fabric bytes per launch from rocprofv3 PMC: " + str(traffic_src),
                      "residency": "the steady-state loop multiplies the same A, B into the same C: the working set "
-                                  f"({w.abytes / 1e6:.0f} MB) stays in the 256 MiB Infinity Cache, so `frac` is algorithmic bytes per "
-                                  "second against the 8 TB/s HBM peak (the metric BASELINE.json defines), not measured HBM "
-                                  "traffic; `hbm_streaming` is the same kernel with B and C streamed from / to HBM"},
+                                  f"({w.abytes / 1e6:.0f} MB) never leaves the chip -- every XCD's slice of B stays in its 4 MiB L2 from launch "
+                                  "to launch where it fits (the L2 is kept across the kernels of a graph: tools/micro/l2_retention.hip), "
+                                  "the rest in the 256 MiB Infinity Cache -- so `frac` is algorithmic bytes per second against the 8 TB/s "
+                                  "HBM peak (the metric BASELINE.json defines), not measured HBM traffic, and `traffic` (PMC under the "
+                                  "profiler: every dispatch starts with cold L2s) is an upper bound for this loop; `hbm_streaming` is the "
+                                  "same kernel with B and C streamed from / to HBM (DESIGN.md section 5.6: L2 / Infinity Cache / HBM regimes)"},
     }
     out["roofline"]["traffic_source"] = ("live" if live is not None and live[0] is not None and live[1] == kernel_tag
                                          else "committed fallback" if traffic is not None else None)
