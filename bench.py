@@ -749,8 +749,8 @@ def run_single(args):
                               "roofline_frac": round(w.abytes / (per * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                               "first_result_equals_single_launch": same, "kernel_tag": capi.last_kernel(),
                               "note": "mispmm_csr_batch_f32: one launch multiplies 8 different dense operands by the same A; algorithmic "
-                                      "bytes per product against the 8 TB/s HBM peak (the operands are Infinity-Cache resident, so the "
-                                      "fraction can exceed what HBM alone would allow)"}
+                                      "bytes per product against the 8 TB/s HBM peak (8 operands = the Infinity-Cache regime of DESIGN.md "
+                                      "section 5.6, where a single launch takes longer than the L2-resident loop behind `value`)"}
             del bs, cs
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, got, args.acc)
