@@ -4,11 +4,14 @@
 // row i + 1 are already in flight, the (col, val) entries of row i + 2 are on their way, and row i's C leaves through a
 // non-temporal store nobody waits for.
 //
-// Why (round 4, profiles/r4/stamps_k512_*.log): at N = 512 the one-row-per-lane-group launch is 12 608 waves for 5 120 wave
+// Why it was built (round 4, profiles/r4/stamps_headline_k128_k512_streamed.log; profiles/r3 for the resident stamps): at N = 512 the one-row-per-lane-group launch is 12 608 waves for 5 120 wave
 // slots, and a wave spends 1.0 us waiting for its 56 (col, val) entries, 2.1 us with B reads in flight and 0.5 us draining its
 // store -- half of a resident wave's life has nothing in flight, and with B streamed from HBM (reads of ~3 us) even less.  The
 // north_star's kernel clause asks for exactly this shape ("one-wavefront-per-row segmented reduction" walking rows; the
 // ancestor is the warp-per-row loop of reference/src/spmm/csr/spmm_csr_k3.cu:9-56).
+// What came of it (profiles/r4/stream_ab.log): equal to the one-row-per-lane-group launch where a lane group has one row,
+// 4-8 % slower where it has two -- these launches are bound by what an XCD pulls over its fabric link, not by a wave's dead time.
+// Compiled into the tuning build only (spmm_stream.hip).
 //
 // Arithmetic is that of row_gather.hpp: one lane owns its C elements and sums a row's products in storage order with the
 // reference's rounding sequence, so REFERENCE mode stays bit-exact; a row past the end of a lane group's run and the slots past

@@ -80,6 +80,5 @@ int main(int argc, char **argv) {
             }
         }
     }
-    // 2 KiB and 4 KiB segments: consecutive wave instructions of one wave walk one segment
     return 0;
 }
