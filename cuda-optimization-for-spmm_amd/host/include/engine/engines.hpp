@@ -46,6 +46,11 @@ namespace cuspmm {
 template <typename DT, typename MT>
 void spmmBSRBf16(SparseMatrixBSR<DT, MT> *a, SparseMatrixBSR<DT, MT> *da, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *db);
 
+// `--ell --gpus n`: A (host, the class's column-major arrays) sharded by rows over n devices in this process through
+// mispmm_multi_ell_f32, B replicated, C slabs gathered according to gatherMode; one record with an extra "ngpus" key
+template <typename DT, typename MT, typename AccT>
+bool spmmELLMultiGpu(int ngpus, int gatherMode, SparseMatrixELL<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref);
+
 // vendor cross-check: rocSPARSE has CSR and COO SpMM wired in; BSR and ELL follow the reference (none)
 CUSPMM_DEFINE_ENGINE(COO, MISPMM_COO_NUM_KERNELS, true)
 CUSPMM_DEFINE_ENGINE(ELL, MISPMM_ELL_NUM_KERNELS, false)

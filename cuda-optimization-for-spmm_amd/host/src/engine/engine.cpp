@@ -54,6 +54,11 @@ void runEngine(EngT *engine, typename EngT::MataT *a, typename EngT::MatbT *b, f
                                                                               b, cpuRes);
         }
 
+        if constexpr (std::is_same_v<ma_t, SparseMatrixELL<typename ma_t::DT, typename ma_t::MT>>) {   // ELL by rows
+            if (engineOptions().gpus > 0)
+                spmmELLMultiGpu<typename ma_t::DT, typename ma_t::MT, double>(engineOptions().gpus, engineOptions().gatherMode, a, b, cpuRes);
+        }
+
         // 3c. `--batch n`: n dense operands multiplied by A in one launch (CSR; the reference multiplies by one dense.in per
         //     process, src/main.cu:185) -- what a caller with several right-hand sides gets for the launch boundary paid once
         if constexpr (std::is_same_v<ma_t, SparseMatrixCSR<typename ma_t::DT, typename ma_t::MT>>) {

@@ -12,7 +12,7 @@
 //                    descriptor, sparse_bsr.cu:138-160, but never enables the check: engine_bsr.hpp:24)
 //   --save <file>    write the last result matrix as text
 //   --dtype <t>      fp32 (default) | bf16: with --bsr and 16-row blocks also run the bf16 MFMA kernels (BASELINE config 4)
-//   --gpus <n>       (--csr) also run the product row-sharded over n GPUs of this node: B replicated, C row slabs
+//   --gpus <n>       (--csr, --ell) also run the product row-sharded over n GPUs of this node: B replicated, C row slabs
 //                    gathered over xGMI; --gather first|peer|rccl|none picks how (default first = into device 0)
 //   --batch <n>      (--csr) also multiply n dense operands (n device copies of B) by A in ONE launch
 //                    (mispmm_csr_batch_f32): one more record, key "batch", steady-state figures per product
@@ -43,7 +43,7 @@ static void printHelp(const char *prog) {
               << "  --vendor-bsr    rocSPARSE cross-check for --bsr as well (square blocks)\n"
               << "  --save <file>   Save the last result matrix\n"
               << "  --dtype <t>     fp32 | bf16 (with --bsr, 16-row blocks: bf16 MFMA kernels as well)\n"
-              << "  --gpus <n>      With --csr: also run row-sharded over n GPUs (B replicated, C slabs gathered)\n"
+              << "  --gpus <n>      With --csr / --ell: also run row-sharded over n GPUs (B replicated, C slabs gathered)\n"
               << "  --batch <n>     With --csr: also multiply n dense operands by A in ONE launch (record key \"batch\")\n"
               << "  --gather <how>  first | peer | rccl | none (default first: slabs copied into device 0)\n"
               << "  -h, --help      Display this help message\n";

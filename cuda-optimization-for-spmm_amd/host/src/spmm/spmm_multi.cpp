@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "engine/engine_csr.hpp"
+#include "engine/engine_ell.hpp"
 #include "engine/wrapper_common.hpp"
 
 namespace cuspmm {
@@ -179,6 +180,137 @@ bool spmmCSRMultiGpu(int ngpus, int gatherMode, SparseMatrixCSR<DT, MT> *a, Dens
     }
 }
 
+// `cuspmm --ell --gpus n`: the ELL SpMM sharded by ROWS over n devices ("ELL by rows"; no sharded
+// counterpart of /root/reference/src/spmm/ell/spmm_ell_k1.cu:10-35 exists) through mispmm_multi_ell_f32.  The class's
+// column-major arrays are turned into the row-major view once on the host (mispmm_ell_colmajor_to_rowmajor_host, as
+// copy2Device does); rows are cut into contiguous ranges balanced by occupied slots.  Timing sections as above.
+template <typename DT, typename MT, typename AccT>
+bool spmmELLMultiGpu(int ngpus, int gatherMode, SparseMatrixELL<DT, MT> *a, DenseMatrix<DT, MT> *b, DenseMatrix<DT, MT> *ref) {
+    if constexpr (!std::is_same_v<DT, float>) {
+        throw std::runtime_error("Not implemented");
+    } else {
+        using clock = std::chrono::high_resolution_clock;
+        auto ms = [](clock::time_point x, clock::time_point z) {
+            return (double)std::chrono::duration_cast<std::chrono::microseconds>(z - x).count() / 1000.0;
+        };
+        assert(!a->onDevice && !b->onDevice && ngpus >= 1);
+        b->toOrdering(ORDERING::ROW_MAJOR);
+        int count = 0, home = 0;
+        mispmmCheckError(mispmm_device_count(&count));
+        mispmmCheckError(mispmm_get_device(&home));
+        if (ngpus > count) throw std::runtime_error("--gpus " + std::to_string(ngpus) + ": this node has " + std::to_string(count) + " device(s)");
+        if (gatherMode == MISPMM_GATHER_ALL_RCCL_EQUAL) gatherMode = MISPMM_GATHER_ALL_RCCL;   // nnz-balanced ranges: grouped broadcasts
+        const uint32_t M = a->numRows, K = a->numCols, N = b->numCols;
+        uint32_t width = 0;
+        mispmmCheckError(mispmm_ell_colmajor_to_rowmajor_host(M, K, a->maxColNnz, a->rowIdxs, a->data, &width, nullptr, nullptr));
+        std::vector<uint32_t> cols((size_t)M * std::max(width, 1u));
+        std::vector<float> vals(cols.size());
+        if (width) mispmmCheckError(mispmm_ell_colmajor_to_rowmajor_host(M, K, a->maxColNnz, a->rowIdxs, a->data, &width, cols.data(), vals.data()));
+        std::vector<uint32_t> occupied((size_t)M + 1, 0), bounds((size_t)ngpus + 1);
+        for (uint32_t r = 0; r < M; ++r) {
+            uint32_t c = 0;
+            for (uint32_t s = 0; s < width; ++s) c += cols[(size_t)r * width + s] != 0xFFFFFFFFu;
+            occupied[r + 1] = occupied[r] + c;
+        }
+        mispmmCheckError(mispmm_shard_rows_by_nnz_host(M, occupied.data(), (uint32_t)ngpus, bounds.data()));
+
+        std::vector<DeviceSlot> slots((size_t)ngpus);            // untimed: every device gets its rows and a replica of B
+        std::vector<int> ordinals((size_t)ngpus);
+        for (int d = 0; d < ngpus; ++d) {
+            DeviceSlot &s = slots[d];
+            s.ordinal = ordinals[d] = (home + d) % count;
+            mispmmCheckError(mispmm_set_device(s.ordinal));
+            mispmmCheckError(mispmm_stream_create(&s.stream));
+            const size_t r0 = bounds[d], n = (size_t)(bounds[d + 1] - bounds[d]) * width;
+            s.colIdxs = allocateBuffer<uint32_t>(n ? n : 1, true);
+            s.vals = allocateBuffer<float>(n ? n : 1, true);
+            s.b = allocateBuffer<float>((size_t)K * N, true);
+            if (n) {
+                copyBuffer(s.colIdxs, true, cols.data() + r0 * width, false, n * sizeof(uint32_t));
+                copyBuffer(s.vals, true, vals.data() + r0 * width, false, n * sizeof(float));
+            }
+            copyBuffer(s.b, true, b->data, false, (size_t)K * N * sizeof(float));
+        }
+        if (ngpus > 1) mispmmCheckError(mispmm_enable_peer_access((uint32_t)ngpus, ordinals.data()));
+        mispmm_comm_t comm = nullptr;
+        if (gatherMode == MISPMM_GATHER_ALL_RCCL) mispmmCheckError(mispmm_comm_create(&comm, (uint32_t)ngpus, ordinals.data()));
+
+        const auto t1 = clock::now();
+        std::vector<mispmm_stream_t> streams;
+        std::vector<const uint32_t *> colIdxs;
+        std::vector<const float *> vs, bs;
+        std::vector<float *> cs;
+        for (DeviceSlot &s : slots) {                            // prolog: C (zero-filled) on every device
+            mispmmCheckError(mispmm_set_device(s.ordinal));
+            s.c = allocateBuffer<float>((size_t)M * N, true);
+            streams.push_back(s.stream);
+            colIdxs.push_back(s.colIdxs);
+            vs.push_back(s.vals);
+            bs.push_back(s.b);
+            cs.push_back(s.c);
+        }
+        const int acc = accModeOf<AccT>();
+        auto launch = [&] {
+            return mispmm_multi_ell_f32((uint32_t)ngpus, ordinals.data(), streams.data(), bounds.data(), K, width, colIdxs.data(), vs.data(),
+                                        bs.data(), N, N, cs.data(), N, MISPMM_KERNEL_AUTO, acc, gatherMode, comm);
+        };
+        auto syncAll = [&] {
+            for (DeviceSlot &s : slots) mispmmCheckError(mispmm_stream_sync(s.stream));
+        };
+        const auto t2 = clock::now();
+        mispmmCheckError(launch());
+        syncAll();
+        const auto t3 = clock::now();
+        auto *res = new DenseMatrix<DT, MT>(M, N, false, ORDERING::ROW_MAJOR);
+        if (gatherMode == MISPMM_GATHER_NONE) {
+            for (int d = 0; d < ngpus; ++d) {
+                mispmmCheckError(mispmm_set_device(slots[d].ordinal));
+                const size_t off = (size_t)bounds[d] * N, n = (size_t)(bounds[d + 1] - bounds[d]) * N;
+                copyBuffer(res->data + off, false, slots[d].c + off, true, n * sizeof(float));
+            }
+        } else {
+            mispmmCheckError(mispmm_set_device(slots[0].ordinal));
+            copyBuffer(res->data, false, slots[0].c, true, (size_t)M * N * sizeof(float));
+        }
+        const auto t4 = clock::now();
+        const bool correct = ref != nullptr && ref->numRows == M && ref->numCols == N &&
+                             allclose<DT>(res->data, ref->data, res->numElements(), REL_TOL, ABS_TOL);
+        delete res;
+        SteadyStats steady;
+        steady.ngpus = ngpus;
+        const int iters = engineOptions().steadyIters;
+        if (iters > 0) {
+            for (int i = 0; i < 10; ++i) mispmmCheckError(launch());
+            syncAll();
+            const auto s0 = clock::now();
+            for (int i = 0; i < iters; ++i) mispmmCheckError(launch());
+            syncAll();
+            const double sec = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - s0).count() * 1e-9 / iters;
+            steady.iters = iters;
+            steady.usPerSpmm = sec * 1e6;
+            steady.gflops = 2.0 * a->numNonZero * N / sec / 1e9;
+            steady.hbmGBps = ((double)M * width * 8.0 + (double)K * N * 4 + (double)M * N * 4) / sec / 1e9;
+            steady.rooflineFrac = steady.hbmGBps / (8000.0 * ngpus);
+        }
+        reportTime(testcase, M, K, a->numNonZero, "ELL", b->ordering, MISPMM_ELL_NUM_KERNELS, ms(t1, t2), ms(t2, t3), ms(t3, t4), correct, &steady);
+        if (comm) mispmmCheckError(mispmm_comm_destroy(comm));
+        for (DeviceSlot &s : slots) {
+            mispmmCheckError(mispmm_set_device(s.ordinal));
+            releaseBuffer(s.colIdxs, true);
+            releaseBuffer(s.vals, true);
+            releaseBuffer(s.b, true);
+            releaseBuffer(s.c, true);
+            mispmmCheckError(mispmm_stream_destroy(s.stream));
+        }
+        mispmmCheckError(mispmm_set_device(home));
+        return correct;
+    }
+}
+
+template bool spmmELLMultiGpu<float, uint32_t, double>(int, int, SparseMatrixELL<float, uint32_t> *, DenseMatrix<float, uint32_t> *,
+                                                       DenseMatrix<float, uint32_t> *);
+template bool spmmELLMultiGpu<double, uint32_t, double>(int, int, SparseMatrixELL<double, uint32_t> *, DenseMatrix<double, uint32_t> *,
+                                                        DenseMatrix<double, uint32_t> *);
 template bool spmmCSRMultiGpu<float, uint32_t, double>(int, int, SparseMatrixCSR<float, uint32_t> *, DenseMatrix<float, uint32_t> *,
                                                        DenseMatrix<float, uint32_t> *);
 template bool spmmCSRMultiGpu<double, uint32_t, double>(int, int, SparseMatrixCSR<double, uint32_t> *, DenseMatrix<double, uint32_t> *,

@@ -289,6 +289,26 @@ def test_cli_row_sharded_run_behind_the_gpus_flag(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_ell_sharded_by_rows_behind_the_gpus_flag(tmp_path):
+    """`cuspmm --ell -k 256 --gpus 1` (BASELINE config 3's operand on the one card of the test box): the ELL product goes
+    through mispmm_multi_ell_f32 (rows cut by occupied slots) and adds one record carrying `ngpus`; every gather mode agrees
+    with the CPU engine."""
+    from mispmm import datasets, formats
+    d = tmp_path / "large_25605"
+    d.mkdir()
+    csr = datasets.load_csr("n4c6-b13", dtype=np.float64)
+    formats.write_ell_colmajor(d / "n4c6-b13_rowind.ell", d / "n4c6-b13_values_colmajor.ell",
+                               formats.csr_to_ell_colmajor(csr, reference_width=True), integer=True)
+    for gather in ("first", "peer", "rccl", "none"):
+        p = run_cli("--ell", "-k", "256", "--gpus", "1", "--gather", gather, "--iters", "20", "-d", str(d))
+        recs = [r for r, _ in records(p.stdout)]
+        multi = [r for r in recs if "ngpus" in r]
+        assert len(multi) == 1 and multi[0]["ngpus"] == "1" and multi[0]["correct"] == "1" and multi[0]["format"] == "ELL", (gather, multi)
+        assert float(multi[0]["gflops"]) > 0
+        assert [r["kernelType"] for r in recs if "ngpus" not in r] == ["0", "1"]
+
+
+@pytest.mark.gpu
 def test_cli_bf16_block_products_behind_the_dtype_flag(tmp_path):
     """`cuspmm --bsr --dtype bf16` (BASELINE config 4 through the CLI): the three bf16 MFMA kernels run after the fp32 ones,
     are checked against the sequential engine on bf16-rounded operands, and their records carry "dtype":"bf16"."""
