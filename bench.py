@@ -91,7 +91,8 @@ def parse():
     p.add_argument("--config", default="headline", choices=["headline", "2", "3", "4", "5"])
     p.add_argument("--matrix", default=None, help="override the configuration's matrix (packed name under data/)")
     p.add_argument("--k-cols", type=int, default=None, help="override the columns of the dense operand (BASELINE 'K')")
-    p.add_argument("--kernel", type=int, default=0, help="kernel id of the format's entry point (0 = library default)")
+    p.add_argument("--kernel", type=int, default=0, help="kernel id of the format's entry point (0 = library default; CSR 7 = the LDS-tile "
+                                                         "kernel mispmm_csr_lds_tile_f32, an experiment)")
     p.add_argument("--acc", default="reference", choices=["reference", "fast"])
     p.add_argument("--launch", default="graph", choices=["graph", "eager"])
     p.add_argument("--bucket", type=int, default=0, help="N>1: steps per C-slab exchange and per bucket hipGraph (0 = 64)")
@@ -176,10 +177,17 @@ class CsrWorkload(Workload):
         self.workload = (f"{matrix} CSR {self.csr.num_rows}x{self.csr.num_cols} nnz {self.csr.nnz} x dense K={n} fp32")
         self.extra_config = {"uniform_row_hint": self.a.uniform_row_nnz if args.kernel in (0, 5) else 0}
         self.has_fast = True
+        # --kernel 7: the LDS-tile kernel (mispmm_csr_lds_tile_f32; an experiment of round 4)
+        self.tiles = ops.DeviceCSRTiles.from_host(self.csr) if args.kernel == 7 else None
+        if self.tiles is not None:
+            self.extra_config.update({"lds_tiles": self.tiles.num_tiles, "b_slices_staged_over_nnz": round(self.tiles.num_listed / self.csr.nnz, 4)})
 
     def step(self, stream, acc=None, pair=None):
         from mispmm import ops
         b, c = pair or (self.b, self.c)
+        if self.tiles is not None:
+            ops.spmm_csr_tiles(self.tiles, b, out=c, acc=acc or self.args.acc, stream=stream)
+            return
         ops.spmm_csr(self.a, b, out=c, kernel=self.args.kernel, acc=acc or self.args.acc, stream=stream)
 
     def host_result(self):

@@ -465,3 +465,100 @@ extern "C" int mispmm_csr_permute_rows_host(uint32_t M, const uint32_t *rowPtrs_
     rowPtrs_out_host[M] = static_cast<uint32_t>(at);
     return MISPMM_OK;
 }
+
+// ---- LDS tiles (mispmm_csr_lds_tile_f32): groups of rows that share B rows, with the list of the distinct columns each group
+// reads.  Greedy growth like the clustering above, but a tile also stops growing when its column list would exceed `maxCols`
+// (the LDS budget of the kernel): a tile keeps taking the unassigned row that shares the most columns with it -- which is the
+// row that adds the fewest new ones.  Rows of a tile sit at consecutive plan positions; an entry's `slot` is the position of
+// its column in its tile's list (< maxCols <= 256: one byte).  Outputs NULL = size query (*numTiles_out, *numListed_out).
+extern "C" int mispmm_csr_tiles_host(uint32_t M, uint32_t K, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host, uint32_t maxRows,
+                                     uint32_t maxCols, uint32_t *numTiles_out, uint32_t *numListed_out, uint32_t *tileRowPtrs_out_host,
+                                     uint32_t *tileColPtrs_out_host, uint32_t *tileCols_out_host, uint32_t *order_out_host,
+                                     uint8_t *slots_out_host) {
+    if (!rowPtrs_host || !numTiles_out || !numListed_out) return fail(MISPMM_ERR_INVALID_ARG, "csr_tiles: null pointer");
+    if (maxRows == 0 || maxRows > 16 || maxCols == 0 || maxCols > 256) return fail(MISPMM_ERR_INVALID_ARG, "csr_tiles: 1..16 rows and 1..256 columns per tile");
+    for (uint32_t r = 0; r < M; ++r) {
+        if (rowPtrs_host[r + 1] < rowPtrs_host[r]) return fail(MISPMM_ERR_INVALID_ARG, "csr_tiles: rowPtrs decrease at row %u", r);
+        if (rowPtrs_host[r + 1] - rowPtrs_host[r] > maxCols) return fail(MISPMM_ERR_UNSUPPORTED, "csr_tiles: row %u alone exceeds a tile's %u columns", r, maxCols);
+    }
+    const uint64_t nnz = rowPtrs_host[M];
+    if (nnz != 0 && !colIdxs_host) return fail(MISPMM_ERR_INVALID_ARG, "csr_tiles: colIdxs is null");
+    for (uint64_t i = 0; i < nnz; ++i)
+        if (colIdxs_host[i] >= K) return fail(MISPMM_ERR_INVALID_ARG, "csr_tiles: column index %u out of range", colIdxs_host[i]);
+    const bool fill = tileRowPtrs_out_host && tileColPtrs_out_host && tileCols_out_host && order_out_host && slots_out_host;
+    std::vector<uint32_t> colPtr(static_cast<size_t>(K) + 1, 0), colRows(nnz);
+    for (uint64_t i = 0; i < nnz; ++i) ++colPtr[colIdxs_host[i] + 1];
+    for (uint32_t c = 0; c < K; ++c) colPtr[c + 1] += colPtr[c];
+    {
+        std::vector<uint32_t> at(colPtr.begin(), colPtr.end() - 1);
+        for (uint32_t r = 0; r < M; ++r)
+            for (uint32_t i = rowPtrs_host[r]; i < rowPtrs_host[r + 1]; ++i) colRows[at[colIdxs_host[i]]++] = r;
+    }
+    constexpr uint32_t kMaxColumnDegree = 64;
+    std::vector<uint8_t> assigned(M, 0);
+    std::vector<uint32_t> gain(M, 0), slotOf(K, 0xFFFFFFFFu), touched, listed;
+    std::vector<std::pair<uint32_t, uint32_t>> heap;
+    uint32_t next_seed = 0, placed = 0, tiles = 0;
+    uint64_t listedTotal = 0, entryAt = 0;
+    if (fill) tileRowPtrs_out_host[0] = tileColPtrs_out_host[0] = 0;
+    while (placed < M) {
+        heap.clear();
+        for (uint32_t r : touched) gain[r] = 0;
+        touched.clear();
+        for (uint32_t c : listed) slotOf[c] = 0xFFFFFFFFu;
+        listed.clear();
+        uint32_t rows = 0;
+        while (rows < maxRows && placed < M) {
+            uint32_t r = 0xFFFFFFFFu;
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const auto top = heap.back();
+                heap.pop_back();
+                if (!assigned[top.second] && gain[top.second] == top.first) {
+                    r = top.second;
+                    break;
+                }
+            }
+            if (r == 0xFFFFFFFFu) {
+                if (rows != 0) break;  // nothing shares a column with the tile any more: close it (a tile of unrelated rows buys nothing)
+                while (next_seed < M && assigned[next_seed]) ++next_seed;
+                r = next_seed;
+            }
+            uint32_t fresh = 0;        // the columns row r would add to the list
+            for (uint32_t i = rowPtrs_host[r]; i < rowPtrs_host[r + 1]; ++i) fresh += slotOf[colIdxs_host[i]] == 0xFFFFFFFFu;
+            if (listed.size() + fresh > maxCols) break;                // (the seed always fits: its row is at most maxCols long)
+            assigned[r] = 1;
+            if (fill) order_out_host[placed] = r;
+            ++placed;
+            ++rows;
+            for (uint32_t i = rowPtrs_host[r]; i < rowPtrs_host[r + 1]; ++i) {
+                const uint32_t c = colIdxs_host[i];
+                if (slotOf[c] == 0xFFFFFFFFu) {
+                    slotOf[c] = static_cast<uint32_t>(listed.size());
+                    listed.push_back(c);
+                    if (colPtr[c + 1] - colPtr[c] <= kMaxColumnDegree)
+                        for (uint32_t j = colPtr[c]; j < colPtr[c + 1]; ++j) {
+                            const uint32_t r2 = colRows[j];
+                            if (assigned[r2]) continue;
+                            if (gain[r2]++ == 0) touched.push_back(r2);
+                            heap.emplace_back(gain[r2], r2);
+                            std::push_heap(heap.begin(), heap.end());
+                        }
+                }
+                if (fill) slots_out_host[entryAt] = static_cast<uint8_t>(slotOf[c]);
+                ++entryAt;
+            }
+        }
+        if (fill) {
+            std::memcpy(tileCols_out_host + listedTotal, listed.data(), listed.size() * sizeof(uint32_t));
+            tileRowPtrs_out_host[tiles + 1] = placed;
+            tileColPtrs_out_host[tiles + 1] = static_cast<uint32_t>(listedTotal + listed.size());
+        }
+        listedTotal += listed.size();
+        ++tiles;
+    }
+    if (listedTotal > 0xFFFFFFFFull) return fail(MISPMM_ERR_UNSUPPORTED, "csr_tiles: column lists exceed 2^32 entries");
+    *numTiles_out = tiles;
+    *numListed_out = static_cast<uint32_t>(listedTotal);
+    return MISPMM_OK;
+}

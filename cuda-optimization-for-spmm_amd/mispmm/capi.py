@@ -58,6 +58,8 @@ SIGNATURES = {
     "mispmm_csr_autotune_plan_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u32, _i, _u32, _c.POINTER(_i),
                                           _c.POINTER(_c.c_float)]),
     "mispmm_autotune_pick": (_i, [_c.POINTER(_c.c_float), _u32, _c.c_float]),
+    "mispmm_csr_tiles_host": (_i, [_u32, _u32, _vp, _vp, _u32, _u32, _c.POINTER(_u32), _c.POINTER(_u32), _vp, _vp, _vp, _vp, _vp]),
+    "mispmm_csr_lds_tile_f32": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_split_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _u32, _i]),
     "mispmm_csr_spans_by_length_host": (_i, [_u32, _vp, _u32, _c.POINTER(_u32), _vp]),
     "mispmm_csr_hybrid_f32": (_i, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i]),

@@ -427,6 +427,55 @@ def spmm_csr_batch(a, bs, outs=None, acc="reference", stream=None):
     return outs
 
 
+@dataclass
+class DeviceCSRTiles:
+    """A CSR with rows of one width grouped into LDS tiles (mispmm_csr_tiles_host): rows that share B rows sit in one tile of
+    <= 16 rows / <= 128 distinct columns, an entry names its column by its position in the tile's list."""
+    num_rows: int
+    num_cols: int
+    nnz: int
+    row_nnz: int
+    num_tiles: int
+    num_listed: int              # sum of the tiles' column lists = B-row slices staged per column part (nnz without sharing)
+    tile_row_ptrs: torch.Tensor
+    tile_col_ptrs: torch.Tensor
+    tile_cols: torch.Tensor
+    slots: torch.Tensor          # uint8 per entry, plan order
+    data: torch.Tensor           # values, plan order
+    row_map: torch.Tensor        # plan position -> C row
+
+    @staticmethod
+    def from_host(csr, device="cuda", max_rows=16, max_cols=128):
+        w = uniform_row_nnz(csr.row_ptrs)
+        if w == 0 or w > 16:
+            raise ValueError("LDS tiles take rows of one width of 1..16 entries")
+        l = capi.lib()
+        rp = np.ascontiguousarray(csr.row_ptrs, dtype=np.uint32)
+        ci = np.ascontiguousarray(csr.col_idxs, dtype=np.uint32)
+        nt, nl = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        head = (csr.num_rows, csr.num_cols, rp.ctypes.data, ci.ctypes.data, int(max_rows), int(max_cols), ctypes.byref(nt), ctypes.byref(nl))
+        capi.check(l.mispmm_csr_tiles_host(*head, None, None, None, None, None))
+        trp, tcp = np.zeros(nt.value + 1, np.uint32), np.zeros(nt.value + 1, np.uint32)
+        tc, order, slots = np.zeros(max(nl.value, 1), np.uint32), np.zeros(csr.num_rows, np.uint32), np.zeros(max(csr.nnz, 1), np.uint8)
+        capi.check(l.mispmm_csr_tiles_host(*head, trp.ctypes.data, tcp.ctypes.data, tc.ctypes.data, order.ctypes.data, slots.ctypes.data))
+        planned = permute_rows(csr, order)
+        return DeviceCSRTiles(csr.num_rows, csr.num_cols, csr.nnz, w, nt.value, nl.value, _dev_u32(trp, device), _dev_u32(tcp, device),
+                              _dev_u32(tc, device), torch.from_numpy(slots).to(device), _dev_f32(planned.data, device), _dev_u32(order, device))
+
+
+def spmm_csr_tiles(a, b, out=None, acc="reference", stream=None):
+    """C = A @ B with the B rows of every tile staged in LDS (mispmm_csr_lds_tile_f32): a: DeviceCSRTiles."""
+    _require_gpu(a.tile_row_ptrs, b)
+    if b.shape[0] != a.num_cols:
+        raise ValueError(f"B has {b.shape[0]} rows, A has {a.num_cols} columns")
+    n = b.shape[1]
+    c = _out(a.num_rows, n, b, out)
+    capi.check(capi.lib().mispmm_csr_lds_tile_f32(_stream_ptr(stream), a.num_rows, a.num_cols, a.row_nnz, a.num_tiles, _p(a.tile_row_ptrs),
+                                                  _p(a.tile_col_ptrs), _p(a.tile_cols), _p(a.slots), _p(a.data), _p(a.row_map), _p(b), n,
+                                                  _dense_ld(b), _p(c), _dense_ld(c), capi.ACC_MODES[acc]))
+    return c
+
+
 def spmm_ell(a, b, out=None, kernel=0, acc="reference", stream=None):
     _require_gpu(a.col_idxs, b)
     if b.shape[0] != a.num_cols:

@@ -232,6 +232,24 @@ int mispmm_csr_autotune_plan_f32(mispmm_stream_t stream, uint32_t M, uint32_t K,
                                  int acc_mode, uint32_t launches, int *use_plan_out, float *times_us_out);
 int mispmm_autotune_pick(const float *times_us, uint32_t n, float min_gain);
 
+/* LDS tiles (round 4): the kernel shape BASELINE.json's north_star names for the row-parallel kernels -- the B rows of a GROUP
+ * of rows staged once into LDS, every row of the group summing from there (ancestor: the shared-memory staging of
+ * src/spmm/csr/spmm_csr_k4.cu:26-62).  Built to have the number; rows of ONE width of <= 16 entries.
+ *   mispmm_csr_tiles_host   HOST, once per upload: greedy grouping into tiles of <= maxRows (<= 16) rows whose DISTINCT columns
+ *                           number <= maxCols (the kernel's LDS budget: 128).  Outputs NULL = size query.  tileRowPtrs[T + 1] /
+ *                           tileColPtrs[T + 1]: a tile's plan rows and its column list in tileCols; order[i] = the row at plan
+ *                           position i (= the kernel's rowMap; permute vals with mispmm_csr_permute_rows_host); slots[nnz]: per
+ *                           entry, in plan order, the position of its column in its tile's list.
+ *   mispmm_csr_lds_tile_f32 C = A * B from those arrays; REFERENCE mode bit-exact (a row keeps its entries in storage order).
+ *                           MISPMM_ERR_UNSUPPORTED for other shapes (column parts that are not whole 64-column groups, ...). */
+int mispmm_csr_tiles_host(uint32_t M, uint32_t K, const uint32_t *rowPtrs_host, const uint32_t *colIdxs_host, uint32_t maxRows,
+                          uint32_t maxCols, uint32_t *numTiles_out, uint32_t *numListed_out, uint32_t *tileRowPtrs_out_host,
+                          uint32_t *tileColPtrs_out_host, uint32_t *tileCols_out_host, uint32_t *order_out_host, uint8_t *slots_out_host);
+int mispmm_csr_lds_tile_f32(mispmm_stream_t stream, uint32_t M, uint32_t K, uint32_t rowNnz, uint32_t numTiles,
+                            const uint32_t *tileRowPtrs, const uint32_t *tileColPtrs, const uint32_t *tileCols, const uint8_t *slots,
+                            const float *vals, const uint32_t *rowMap, const float *B, uint32_t N, uint32_t ldb, float *C, uint32_t ldc,
+                            int acc_mode);
+
 /* Several products with the same A in ONE launch: C_list[i] = A * B_list[i], i < batch (HOST arrays of device
  * pointers; every operand N columns wide with leading dimensions ldb / ldc).  Same arithmetic and results as
  * `batch` calls of mispmm_csr_f32 (kernel 5) / mispmm_csr_uniform_f32 (uniformRowNnz > 0: rowPtrs may be NULL),

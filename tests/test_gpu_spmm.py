@@ -80,6 +80,43 @@ def test_production_library_never_takes_the_persistent_launch():
         assert "row_gather" in capi.last_kernel(), (n, capi.last_kernel())
 
 
+@pytest.mark.parametrize("name,n", [("n4c6-b13", 128), ("n4c6-b13", 512), ("n3c5-b6", 64)])
+def test_csr_lds_tiles_match_oracle(oracle, name, n):
+    """mispmm_csr_lds_tile_f32 (the north_star's kernel shape: the B rows of a group of rows staged once in LDS): tiles built
+    by mispmm_csr_tiles_host (<= 16 rows, <= 128 distinct columns, every row in exactly one tile, an entry's slot names its
+    column), product bit-exact in REFERENCE mode (a row keeps its entries in storage order) and within 1e-5 in FAST mode;
+    strided operands keep their gap columns."""
+    csr = datasets.load_csr(name)
+    a = ops.DeviceCSRTiles.from_host(csr)
+    trp, tcp = a.tile_row_ptrs.cpu().numpy().view(np.uint32), a.tile_col_ptrs.cpu().numpy().view(np.uint32)
+    order, cols, slots = a.row_map.cpu().numpy().view(np.uint32), a.tile_cols.cpu().numpy().view(np.uint32), a.slots.cpu().numpy()
+    assert sorted(order.tolist()) == list(range(csr.num_rows)) and trp[-1] == csr.num_rows and tcp[-1] == a.num_listed
+    assert np.all(np.diff(trp.astype(np.int64)) <= 16) and np.all(np.diff(trp.astype(np.int64)) >= 1) and np.all(np.diff(tcp.astype(np.int64)) <= 128)
+    w = a.row_nnz
+    for t in (0, a.num_tiles // 2, a.num_tiles - 1):          # an entry's slot names its column in its tile's list
+        for i in range(trp[t], trp[t + 1]):
+            r = order[i]
+            assert np.array_equal(cols[tcp[t]:tcp[t + 1]][slots[i * w:(i + 1) * w]], csr.col_idxs[csr.row_ptrs[r]:csr.row_ptrs[r + 1]])
+        assert len(set(cols[tcp[t]:tcp[t + 1]].tolist())) == tcp[t + 1] - tcp[t]
+    assert a.num_listed < csr.nnz                               # rows of a tile do share B rows
+    b = synth.dense_b(csr.num_cols, n)
+    ref = oracle.spmm_csr(csr.row_ptrs, csr.col_idxs, csr.data, b)
+    got = ops.spmm_csr_tiles(a, dev(b)).cpu().numpy()
+    assert "csr_lds_tile" in capi.last_kernel()
+    assert np.array_equal(got, ref)
+    assert_fast_close(ops.spmm_csr_tiles(a, dev(b), acc="fast").cpu().numpy(), ref, abs_scale(csr, b))
+    bw = torch.full((csr.num_cols, n + 8), 3.0, device="cuda")
+    bw[:, :n] = dev(b)
+    cw = torch.full((csr.num_rows, n + 4), -7.0, device="cuda")
+    ops.spmm_csr_tiles(a, bw[:, :n], out=cw[:, :n])
+    assert np.array_equal(cw[:, :n].cpu().numpy(), ref) and bool((cw[:, n:] == -7.0).all())
+    for bad in (40, 96):                                        # column parts that are not whole 64-column groups are declined
+        with pytest.raises(capi.MispmmError):
+            ops.spmm_csr_tiles(a, dev(synth.dense_b(csr.num_cols, bad)))
+    with pytest.raises(ValueError):
+        ops.DeviceCSRTiles.from_host(datasets.load_csr("delaunay_n12"))
+
+
 # --------------------------------------------------------------------------- CSR
 CSR_CASES = [("Hamrle1", [1, 3, 32]), ("n3c5-b6", [8, 21]), ("qh1484", [64, 130]), ("delaunay_n12", [128]),
              ("GL7d25", [64, 100]), ("ACTIVSg10K", [128]), ("n4c6-b13", [128, 256, 512, 515])]
