@@ -16,7 +16,10 @@ namespace mispmm {
 
 constexpr uint32_t kTileCols = 128;   // distinct columns per tile = the LDS budget (x 256 B = 32 KiB); a tile holds <= 16 rows (one per lane group)
 
-template <class Acc, int W>
+// DMA: the slices go from the buffer load straight into LDS (buffer_load_dwordx4 ... lds: a wave's four lane groups stage four
+// CONSECUTIVE list positions = 1 KiB contiguous, exactly what one LDS-DMA instruction writes) instead of through registers and
+// ds_write_b128 -- measured beside the register form (profiles/r4/lds_tile_ab.log).
+template <class Acc, int W, bool DMA>
 __global__ __launch_bounds__(256, 3) void csr_lds_tile_kernel(
     const uint32_t *__restrict__ tileRowPtrs, const uint32_t *__restrict__ tileColPtrs, const uint32_t *__restrict__ tileCols,
     const uint8_t *__restrict__ slots, const float *__restrict__ vals, const float *__restrict__ B, uint32_t b_bytes, uint32_t width,
@@ -50,16 +53,30 @@ __global__ __launch_bounds__(256, 3) void csr_lds_tile_kernel(
         const uint32_t j = g + 16u * k;
         cidx[k] = tileCols[d0 + min(j, D - 1u)];
     }
-    f32x4 v[JMAX];
+    if constexpr (DMA) {
+        using lds_ptr_t = __attribute__((address_space(3))) void *;
+        const uint32_t wave_first = (threadIdx.x >> 6) * 4u;          // the wave's first list position of pass k = 0
 #pragma unroll
-    for (int k = 0; k < JMAX; ++k) {
-        const uint32_t j = g + 16u * k;
-        v[k] = buffer_load_vec<VEC>(brs, j < D ? cidx[k] * ldb4 + lane_off : kDropLoad, 0);
-    }
+        for (int k = 0; k < JMAX; ++k) {
+            const uint32_t j = g + 16u * k;
+            // LDS destination = base + lane-in-wave * 16: position wave_first + 16 k of the tile image, 1 KiB per wave instruction
+            const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tile)) + (wave_first + 16u * k) * (G * 16u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, reinterpret_cast<lds_ptr_t>(static_cast<uintptr_t>(lds_base)), 16,
+                                                     j < D ? cidx[k] * ldb4 + lane_off : kDropLoad, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slices have landed
+    } else {
+        f32x4 v[JMAX];
 #pragma unroll
-    for (int k = 0; k < JMAX; ++k) {
-        const uint32_t j = g + 16u * k;
-        if (j < D) tile[j * G + lane] = v[k];
+        for (int k = 0; k < JMAX; ++k) {
+            const uint32_t j = g + 16u * k;
+            v[k] = buffer_load_vec<VEC>(brs, j < D ? cidx[k] * ldb4 + lane_off : kDropLoad, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < JMAX; ++k) {
+            const uint32_t j = g + 16u * k;
+            if (j < D) tile[j * G + lane] = v[k];
+        }
     }
     __syncthreads();
     typename Acc::T acc[VEC];
@@ -94,14 +111,22 @@ static void launch_tiles(hipStream_t st, uint32_t numTiles, const uint32_t *tile
     const uint32_t chunk = ceil_div(numTiles, 1u << t.log2p);
     dim3 grid(8u * chunk, ceil_div(cols_per_part, 64u));
     const uint32_t b_bytes = static_cast<uint32_t>(static_cast<uint64_t>(K) * ldb * 4u), c_bytes = static_cast<uint32_t>(static_cast<uint64_t>(M) * ldc * 4u);
-    note_kernel("csr_lds_tile<%s> xcd %ux%u, %u tiles", acc_tag<Acc>(), 1u << t.log2p, t.q, numTiles);
-#define MISPMM_TILE_LAUNCH(WW)                                                                                                          \
-    hipLaunchKernelGGL((csr_lds_tile_kernel<Acc, WW>), grid, dim3(256), 0, st, tileRowPtrs, tileColPtrs, tileCols, slots, vals, B, b_bytes, \
+    // staging through registers (ds_write_b128) or by LDS-DMA: MISPMM_TILE_DMA=0 / 1 in the tuning build (default: DMA, the faster)
+    static const bool dma = knob_int("MISPMM_TILE_DMA", 1) != 0;
+    note_kernel("csr_lds_tile<%s,%s> xcd %ux%u, %u tiles", acc_tag<Acc>(), dma ? "lds-dma" : "ds_write", 1u << t.log2p, t.q, numTiles);
+#define MISPMM_TILE_LAUNCH(WW, DD)                                                                                                          \
+    hipLaunchKernelGGL((csr_lds_tile_kernel<Acc, WW, DD>), grid, dim3(256), 0, st, tileRowPtrs, tileColPtrs, tileCols, slots, vals, B, b_bytes, \
                        width, ldb, numTiles, t.log2p | (chunk << 8), cols_per_part, N, rowMap, C, c_bytes, ldc)
-    if (width > 14) MISPMM_TILE_LAUNCH(16);
-    else if (width > 12) MISPMM_TILE_LAUNCH(14);
-    else if (width > 8) MISPMM_TILE_LAUNCH(12);
-    else MISPMM_TILE_LAUNCH(8);
+#define MISPMM_TILE_PICK(DD)                     \
+    do {                                         \
+        if (width > 14) MISPMM_TILE_LAUNCH(16, DD);      \
+        else if (width > 12) MISPMM_TILE_LAUNCH(14, DD); \
+        else if (width > 8) MISPMM_TILE_LAUNCH(12, DD);  \
+        else MISPMM_TILE_LAUNCH(8, DD);                  \
+    } while (0)
+    if (dma) MISPMM_TILE_PICK(true);
+    else MISPMM_TILE_PICK(false);
+#undef MISPMM_TILE_PICK
 #undef MISPMM_TILE_LAUNCH
 }
 
