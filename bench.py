@@ -821,7 +821,7 @@ def run_multi(args):
     elif fmt == "ell":
         operand = ops.colmajor_ell_to_rowmajor(formats.csr_to_ell_colmajor(csr))
         abytes = datasets.ell_algorithmic_bytes(csr.num_rows, operand.width, csr.num_cols, n)
-        shard_bounds = mdist.ShardedEllSpmm._partition(None, operand, world)
+        shard_bounds = mdist.ShardedEllSpmm._partition(operand, world)
         kind, esize = "ELL", 4
 
         def make_job(mode, **kw):
@@ -834,7 +834,7 @@ def run_multi(args):
             return (r1 - r0) * operand.width * 8
     else:
         operand = formats.csr_to_bsr(csr, 16)
-        shard_bounds = mdist.ShardedBsrcSlotsSpmm._partition(None, operand, world)
+        shard_bounds = mdist.ShardedBsrcSlotsSpmm._partition(operand, world)
         kind, esize = "BSR block 16", 2
         abytes = None                                             # the bytes of the kernel's operand: summed over the shards below
 

@@ -74,7 +74,8 @@ class ShardedCsrSpmm:
     b_dtype = torch.float32
 
     # -- hooks -------------------------------------------------------------------------------------
-    def _partition(self, csr, world):
+    @staticmethod
+    def _partition(csr, world):
         """Row bounds of the shards, nnz-balanced (int64 array of world + 1 C-row indices)."""
         return shard_bounds(csr.row_ptrs, world)
 
@@ -380,7 +381,8 @@ class ShardedEllSpmm(ShardedCsrSpmm):
         super().__init__(ell, n_cols, device, kernel=kernel, acc=acc, bucket=bucket, compute=compute, exchange=exchange,
                          debug_sentinel=debug_sentinel, batch=1)
 
-    def _partition(self, ell, world):
+    @staticmethod
+    def _partition(ell, world):
         cols = np.asarray(ell.col_idxs, dtype=np.uint32).reshape(ell.num_rows, -1)
         occupied = np.concatenate([[0], np.cumsum((cols != 0xFFFFFFFF).sum(axis=1))]).astype(np.uint32)
         return shard_bounds(occupied, world)
@@ -409,7 +411,8 @@ class ShardedBsrcSlotsSpmm(ShardedCsrSpmm):
         super().__init__(bsr, n_cols, device, kernel=0, acc="reference", bucket=bucket, compute=compute, exchange=exchange,
                          debug_sentinel=debug_sentinel, batch=1)
 
-    def _partition(self, bsr, world):
+    @staticmethod
+    def _partition(bsr, world):
         return shard_bounds(bsr.block_row_ptrs, world) * 16              # C rows
 
     def _make_local(self, bsr, r0, r1):
