@@ -388,3 +388,57 @@ def test_row_clustering_and_permutation_helpers():
     assert l.mispmm_csr_plan_f32(None, 4, 4, 1, None, one, one, 0, one, 1, lst, 8, 8, lst, 8, 0) == capi.ERR_INVALID_ARG  # no rowPtrs, not uniform
     assert l.mispmm_csr_plan_f32(None, 4, 4, 1, one, one, one, 0, one, 0, lst, 8, 8, lst, 8, 0) == capi.OK                # empty batch
     assert l.mispmm_csr_cluster_rows_host(4, 4, None, None, 2, None, None, None) == capi.ERR_INVALID_ARG
+
+
+def test_autotune_pick_is_a_pure_function():
+    """mispmm_autotune_pick (no GPU needed): the default (candidate 0) is kept unless another is at least min_gain faster; a
+    candidate that could not run (inf), a zero or a NaN never wins; the same timings always give the same choice."""
+    l = capi.lib()
+
+    def pick(times, gain=0.02):
+        arr = (ctypes.c_float * len(times))(*times)
+        return l.mispmm_autotune_pick(arr, len(times), ctypes.c_float(gain))
+    assert pick([12.6, 11.1]) == 1 and pick([3.47, 3.69]) == 0 and pick([13.60, 12.99]) == 1
+    assert pick([10.0, 9.85]) == 0 and pick([10.0, 9.79]) == 1
+    assert pick([10.0, float("inf")]) == 0 and pick([float("inf"), 5.0]) == 1 and pick([10.0, float("nan")]) == 0
+    assert pick([10.0, 0.0]) == 0 and pick([10.0, 9.0, 8.0]) == 2 and pick([10.0, 9.0], 0.2) == 0
+    assert l.mispmm_autotune_pick(None, 0, ctypes.c_float(0.02)) == -1
+    assert len({pick([12.6, 11.1]) for _ in range(10)}) == 1
+
+
+def test_lds_tile_builder_invariants():
+    """mispmm_csr_tiles_host (host only): every row in exactly one tile, tiles of at most maxRows rows and maxCols DISTINCT
+    columns, an entry's slot names its column in its tile's list, rows of a tile do share columns (fewer listed columns than
+    entries) -- on n4c6-b13 and on a matrix whose rows share nothing (every tile is one seed's worth of unrelated rows)."""
+    from mispmm import datasets
+    l = capi.lib()
+    for csr, shares in ((datasets.load_csr("n4c6-b13"), True), (datasets.load_csr("n3c5-b6"), True)):
+        rp = np.ascontiguousarray(csr.row_ptrs, dtype=np.uint32)
+        ci = np.ascontiguousarray(csr.col_idxs, dtype=np.uint32)
+        for max_rows, max_cols in ((16, 128), (4, 24), (16, 256)):
+            nt, nl = ctypes.c_uint32(0), ctypes.c_uint32(0)
+            head = (csr.num_rows, csr.num_cols, rp.ctypes.data, ci.ctypes.data, max_rows, max_cols, ctypes.byref(nt), ctypes.byref(nl))
+            capi.check(l.mispmm_csr_tiles_host(*head, None, None, None, None, None))
+            trp, tcp = np.zeros(nt.value + 1, np.uint32), np.zeros(nt.value + 1, np.uint32)
+            tc, order, slots = np.zeros(nl.value, np.uint32), np.zeros(csr.num_rows, np.uint32), np.zeros(csr.nnz, np.uint8)
+            capi.check(l.mispmm_csr_tiles_host(*head, trp.ctypes.data, tcp.ctypes.data, tc.ctypes.data, order.ctypes.data, slots.ctypes.data))
+            assert sorted(order.tolist()) == list(range(csr.num_rows)) and trp[0] == 0 and trp[-1] == csr.num_rows and tcp[-1] == nl.value
+            rows_per, cols_per = np.diff(trp.astype(np.int64)), np.diff(tcp.astype(np.int64))
+            assert rows_per.min() >= 1 and rows_per.max() <= max_rows and cols_per.max() <= max_cols
+            at = 0
+            for t in range(nt.value):
+                listed = tc[tcp[t]:tcp[t + 1]]
+                assert len(set(listed.tolist())) == len(listed)
+                for i in range(trp[t], trp[t + 1]):
+                    r = order[i]
+                    n = int(rp[r + 1] - rp[r])
+                    assert np.array_equal(listed[slots[at:at + n]], ci[rp[r]:rp[r + 1]])
+                    at += n
+            assert at == csr.nnz and nl.value <= csr.nnz
+            if max_cols >= 128:
+                assert (nl.value < csr.nnz) == shares
+    one = np.array([0, 3], dtype=np.uint32)
+    cols3 = np.array([0, 1, 2], dtype=np.uint32)
+    nt, nl = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    assert l.mispmm_csr_tiles_host(1, 3, one.ctypes.data, cols3.ctypes.data, 16, 2, ctypes.byref(nt), ctypes.byref(nl), None, None, None, None, None) == capi.ERR_UNSUPPORTED
+    assert l.mispmm_csr_tiles_host(1, 3, one.ctypes.data, cols3.ctypes.data, 17, 128, ctypes.byref(nt), ctypes.byref(nl), None, None, None, None, None) == capi.ERR_INVALID_ARG
