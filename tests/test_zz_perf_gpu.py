@@ -25,7 +25,7 @@ CLI = os.path.join(ROOT, "cuda-optimization-for-spmm_amd", "cuspmm")
 
 # resident loop (`roofline.frac`) and HBM-streamed loop (`hbm_streaming.frac`) per BASELINE configuration: kept figure, floor
 RESIDENT = {"headline": (0.605, 0.55), "2": (0.21, 0.19), "3": (0.72, 0.66), "4": (0.537, 0.49), "5": (0.63, 0.575)}
-STREAMED = {"headline": (0.338, 0.31), "2": (0.16, 0.14), "3": (0.337, 0.30), "4": (0.46, 0.42), "5": (0.416, 0.38)}
+STREAMED = {"headline": (0.338, 0.30), "2": (0.16, 0.14), "3": (0.337, 0.30), "4": (0.46, 0.41), "5": (0.41, 0.36)}
 
 
 def _records(stdout):
